@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""Benchmark: Mpix/s per PIV frame pair through the 2-level Horn-Schunck pyramid at 4096x4096.
+
+One step = one frame pair through the whole hot path with the reference's example parameters
+(Gaussian pre-filter Fs 3.4, 2 pyramid levels, alphas [21, 45], 100 Jacobi sweeps per level), inputs
+already resident in HBM as float32.  N GPUs = N ranks, each with its own pairs (weak scaling); with
+N > 1 every pair's flow field is gathered to rank 0 over RCCL, overlapped with the next pair.
+
+    python bench.py --gpus 1 --steps 10 --warmup 2
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "opticalflow-ri_amd")]
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak
+HS_BYTES_PER_PX_SWEEP = 28.0   # read U,V,fx,fy,ft + write U,V, float32
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--size", type=int, default=4096, help="frame edge in pixels (benchmark config: 4096)")
+    ap.add_argument("--niter", type=int, default=100)
+    ap.add_argument("--fuse", type=int, default=0, help="Jacobi sweeps per launch (0 = automatic)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--with-transfer", action="store_true", help="also report the rate including H2D/D2H copies")
+    return ap.parse_args()
+
+
+def cpu_baseline(niter):
+    """The CPU oracle (NumPy/SciPy restatement of the reference's Numba/SciPy path, single thread) on a
+    bounded sample of the same workload: the identical pipeline on one 1024x1024 synthetic pair."""
+    from piv_synth import synth_piv
+    from oracle import hs as ohs, pyramid as opyr
+    n = 1024
+    a, b = synth_piv(n, n, seed=0)
+    a, b = a.astype(np.float32), b.astype(np.float32)
+    t = time.perf_counter()
+    opyr.pyramidal_flow(a, b, 3.4, ohs.HSAdapter([21, 45], niter), 2, 1, None)
+    dt = time.perf_counter() - t
+    return {"value": n * n / dt / 1e6, "unit": "Mpix/s", "cores": 1, "kind": "port",
+            "sample": "same 2-level HS pipeline (Fs3.4, alphas [21,45], %d sweeps/level) on one 1024x1024 synthetic pair, "
+                      "%.1f s, NumPy/SciPy single thread" % (niter, dt)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    dist = torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    import _ofri
+    from piv_synth import synth_piv
+    from HornSchunck import HSOpticalFlowAlgoAdapter
+    from GenericPyramidalOpticalFlow import pyramidal_flow_device
+
+    H = W = args.size
+    if world > 1:
+        stream = torch.cuda.Stream(device=local)
+        torch.cuda.set_stream(stream)
+        ctx = _ofri.Context(local, stream.cuda_stream)
+    else:
+        ctx = _ofri.Context(local)
+    ctx.set_hs_fuse(args.fuse)
+
+    # synthetic pair of this rank, resident in HBM as float32 before the timed region
+    f0, f1 = synth_piv(H, W, seed=rank)
+    lib = _ofri.lib()
+    u0, u1 = ctx.upload(f0, np.uint8), ctx.upload(f1, np.uint8)
+    im0, im1 = ctx.empty((H, W)), ctx.empty((H, W))
+    _ofri.check(lib.ofri_u8_to_f32(ctx.handle, u0.ptr, im0.ptr, H * W))
+    _ofri.check(lib.ofri_u8_to_f32(ctx.handle, u1.ptr, im1.ptr, H * W))
+    ctx.sync()
+
+    gather = world > 1 and not args.no_gather
+    if gather:
+        out_t = [torch.empty((2, H, W), dtype=torch.float32, device="cuda") for _ in range(2)]
+        recv = [torch.empty((2, H, W), dtype=torch.float32, device="cuda") for _ in range(world)] if rank == 0 else None
+        comm_stream = torch.cuda.Stream(device=local)
+        pending = []
+
+    def step(i):
+        Ua, Va = pyramidal_flow_device(im0, im1, 3.4, HSOpticalFlowAlgoAdapter([21, 45], args.niter), 2, 1, None)
+        if gather:
+            buf = out_t[i & 1]
+            if len(pending) >= 2:
+                pending.pop(0).wait()           # the buffer we are about to overwrite has been sent
+            _ofri.check(lib.ofri_copy(ctx.handle, buf[0].data_ptr(), Ua.ptr, Ua.nbytes))
+            _ofri.check(lib.ofri_copy(ctx.handle, buf[1].data_ptr(), Va.ptr, Va.nbytes))
+            comm_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(comm_stream):
+                pending.append(dist.gather(buf, recv, dst=0, async_op=True))
+        return Ua, Va
+
+    def fence():
+        if gather:
+            while pending:
+                pending.pop(0).wait()
+            torch.cuda.current_stream().wait_stream(comm_stream)
+        if world > 1:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+        else:
+            ctx.sync()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    ctx.prof_enable(True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    fence()
+    dt = time.perf_counter() - t0
+    recs = ctx.prof_records()
+    ctx.prof_enable(False)
+
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    result = None
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = world * H * W * args.steps / dt / 1e6
+        # dominant kernel: the Jacobi sweep launches of the full-resolution level
+        full = [r for r in recs if r[3] == H and r[4] == W]
+        ms = sum(r[0] for r in full)
+        launches = sum(r[1] for r in full)
+        sweeps = sum(r[2] for r in full)
+        per_launch_ms = ms / max(launches, 1)
+        sweeps_per_launch = sweeps / max(launches, 1)
+        alg_bytes = HS_BYTES_PER_PX_SWEEP * H * W * sweeps_per_launch
+        achieved = alg_bytes / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
+        result = {
+            "metric": "Mpix/s per PIV frame pair (HS 100-iter @4096^2)",
+            "value": value, "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "HS Fs3.4, 2-level pyramid, %dx%d synthetic Poiseuille pair, alphas [21,45], "
+                                   "%d sweeps/level" % (H, W, args.niter),
+                       "pairs_per_step_per_gpu": 1, "flow_gather": "rccl gather to rank 0, overlapped" if gather else "none",
+                       "hs_sweeps_per_launch": sweeps_per_launch},
+            "roofline": {"bound": "hbm", "kernel": "hs_jacobi_sweep@%dx%d" % (H, W), "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "launch_ms": per_launch_ms, "launches_timed": launches,
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "hs_level2_share_of_step": (ms / args.steps) / ms_per_step if ms_per_step > 0 else None},
+        }
+    if args.with_transfer and rank == 0 and world == 1:
+        t = time.perf_counter()
+        for i in range(3):
+            a_d, b_d = ctx.upload(f0, np.uint8), ctx.upload(f1, np.uint8)
+            _ofri.check(lib.ofri_u8_to_f32(ctx.handle, a_d.ptr, im0.ptr, H * W))
+            _ofri.check(lib.ofri_u8_to_f32(ctx.handle, b_d.ptr, im1.ptr, H * W))
+            Ua, Va = step(i)
+            Ua.numpy(); Va.numpy()
+        result["with_transfer_mpix_s"] = H * W * 3 / (time.perf_counter() - t) / 1e6
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(args.niter)
+    elif rank == 0:
+        result["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

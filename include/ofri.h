@@ -1,0 +1,137 @@
+/*
+ * ofri.h - C ABI of libofri_hip.so, the MI355X (gfx950) dense optical-flow engine.
+ *
+ * The reference (alexlib/OpticalFlow-RI) has no native/FFI boundary: its seam is the Python adapter
+ * protocol  U, V, err = adapter.compute(im1, im2, U, V)  (src/GenericPyramidalOpticalFlow.py:256-290,
+ * called at :406-411).  This header is what a ctypes binding underneath that protocol calls; every
+ * entry point names the reference function it replaces.
+ *
+ * Conventions
+ *  - every function returns 0 on success, a negative OFRI_E* code on failure; ofri_last_error()
+ *    returns the calling thread's last message.  Nothing throws across this boundary.
+ *  - images and flow fields are float32, row-major, dense (pitch == cols), shape (rows, cols);
+ *    U is the x / column component, V the y / row component, as in the reference.
+ *  - pointers named *_host are host memory; every other image pointer is DEVICE memory on the
+ *    context's GPU (from ofri_alloc, hipMalloc, or a torch tensor's data_ptr()).
+ *  - work is enqueued on the context's HIP stream and is asynchronous unless the function hands a
+ *    value back to the host (err_host, iters_host, ofri_download, ofri_ctx_sync).
+ *  - one host thread per context at a time; contexts are independent (one per GPU / per process).
+ */
+#ifndef OFRI_H
+#define OFRI_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OFRI_OK          0
+#define OFRI_EINVAL     -1   /* bad argument (null pointer, non-positive size, unsupported option) */
+#define OFRI_EHIP       -2   /* a HIP runtime call failed; message carries hipGetErrorString */
+#define OFRI_ENOMEM     -3   /* device allocation failed */
+#define OFRI_ENODEVICE  -4   /* no usable GPU */
+
+typedef struct ofri_ctx ofri_ctx;
+typedef struct ofri_event ofri_event;
+
+/* ---- library / context --------------------------------------------------------------------- */
+int         ofri_version(void);
+const char *ofri_last_error(void);
+int         ofri_device_count(int *count);
+/* stream == NULL: the context creates and owns a non-blocking stream; otherwise it borrows the
+ * caller's hipStream_t (e.g. torch.cuda.current_stream().cuda_stream).  Replaces the
+ * cl.Context / cl.CommandQueue creation of Farneback_PyCL.py:98-99,230 and
+ * denseLucasKanade_PyCL.py:40-41 (platformID/deviceID -> HIP device ordinal). */
+int ofri_ctx_create(int device, void *stream, ofri_ctx **out);
+int ofri_ctx_destroy(ofri_ctx *ctx);
+int ofri_ctx_sync(ofri_ctx *ctx);
+int ofri_ctx_stream(ofri_ctx *ctx, void **stream);
+
+/* pooled device memory: ofri_free returns the block to the context's pool, so steady-state
+ * pipelines make no hipMalloc calls.  ofri_pool_trim releases the pool to the driver. */
+int ofri_alloc(ofri_ctx *ctx, size_t bytes, void **dptr);
+int ofri_free(ofri_ctx *ctx, void *dptr);
+int ofri_pool_trim(ofri_ctx *ctx);
+int ofri_upload(ofri_ctx *ctx, void *dst, const void *src_host, size_t bytes);     /* blocking */
+int ofri_download(ofri_ctx *ctx, void *dst_host, const void *src, size_t bytes);   /* blocking */
+int ofri_copy(ofri_ctx *ctx, void *dst, const void *src, size_t bytes);            /* device->device */
+int ofri_zero(ofri_ctx *ctx, void *dst, size_t bytes);
+/* uint8 / uint16 grey image -> float32 on device (examples do imread(...).astype(np.float32),
+ * examples/PyHSchunck_Fs3_4.py:129-130) */
+int ofri_u8_to_f32(ofri_ctx *ctx, const unsigned char *src, float *dst, size_t n);
+int ofri_u16_to_f32(ofri_ctx *ctx, const unsigned short *src, float *dst, size_t n);
+
+/* HIP events on the context's stream, for timing kernels from a host language */
+int ofri_event_create(ofri_ctx *ctx, ofri_event **ev);
+int ofri_event_record(ofri_ctx *ctx, ofri_event *ev);
+int ofri_event_elapsed_ms(ofri_event *start, ofri_event *stop, float *ms);          /* syncs on stop */
+int ofri_event_destroy(ofri_event *ev);
+
+/* ---- Gaussian pre-filter -------------------------------------------------------------------- */
+/* convolveSeparableFilter (src/gaussian_filter.py:54-85): rows pass then columns pass, symmetric
+ * reflect border (edge sample repeated), float32 sequential accumulation.  dst may equal src (the
+ * reference filters in place).  taps_host: ntaps float32 values (ntaps odd, <= 127,
+ * ntaps/2 <= min(rows, cols)). */
+int ofri_gauss_sep(ofri_ctx *ctx, const float *src, float *dst, int rows, int cols,
+                   const float *taps_host, int ntaps);
+/* prepareGaussianKernel (src/gaussian_filter.py:47-52) into taps_host[ksize] (host-side, no GPU) */
+int ofri_gauss_taps(double sigma, int ksize, float *taps_host);
+
+/* ---- Horn-Schunck --------------------------------------------------------------------------- */
+/* computeDerivatives(im1=first, im2=second) (src/HornSchunck.py:107-127), 'mirror' border.
+ * The adapter chain passes frame 1 as `first` and frame 0 as `second` (HornSchunck.py:37,73,84). */
+int ofri_hs_derivs(ofri_ctx *ctx, const float *first, const float *second,
+                   float *fx, float *fy, float *ft, int rows, int cols);
+/* HS_helper + HS_helper2 (src/HornSchunck.py:52-71): niter Jacobi sweeps, result left in U, V.
+ * Several sweeps are fused per launch (temporal blocking); ofri_hs_set_fuse(ctx, t) pins the number
+ * of sweeps per launch (t = 0: automatic, t = 1: one launch per sweep). */
+int ofri_hs_iterate(ofri_ctx *ctx, float *U, float *V, const float *fx, const float *fy,
+                    const float *ft, float alpha, int niter, int rows, int cols);
+int ofri_hs_set_fuse(ofri_ctx *ctx, int sweeps_per_launch);
+/* Timing of the sweep launches, for roofline reports: while enabled, every ofri_hs_iterate call
+ * brackets its sweep launches with two HIP events on the context's stream and appends a record.
+ * ofri_prof_read syncs on record idx and returns its elapsed time, the number of kernel launches and
+ * of Jacobi sweeps they covered, and the field shape.  ofri_prof_enable(ctx, 0/1) also clears records. */
+int ofri_prof_enable(ofri_ctx *ctx, int on);
+int ofri_prof_count(ofri_ctx *ctx, int *count);
+int ofri_prof_read(ofri_ctx *ctx, int idx, float *ms, int *launches, int *sweeps, int *rows, int *cols);
+/* HS as reached through HSOpticalFlowAlgoAdapter.compute (src/HornSchunck.py:35-37,73-105):
+ * derivatives, niter sweeps from (U_in, V_in), error (|Un-U_in|_F + |Vn-V_in|_F)/(rows*cols).
+ * U_out/V_out must not alias U_in/V_in.  err_host may be NULL (then nothing blocks). */
+int ofri_hs_compute(ofri_ctx *ctx, const float *frame0, const float *frame1,
+                    const float *U_in, const float *V_in, float *U_out, float *V_out,
+                    float alpha, int niter, int rows, int cols, double *err_host);
+
+/* ---- pyramid glue --------------------------------------------------------------------------- */
+/* imresize (src/GenericPyramidalOpticalFlow.py:67-68): Pillow's scale-aware bicubic (a = -0.5) on
+ * float32: horizontal then vertical pass, float64 accumulation, float32 intermediate. */
+int ofri_resize_bicubic(ofri_ctx *ctx, const float *src, int rows_in, int cols_in,
+                        float *dst, int rows_out, int cols_out);
+/* Pillow BILINEAR resize used by Farneback_PyCL.imresize (src/Farneback_PyCL.py:62-63) */
+int ofri_resize_bilinear(ofri_ctx *ctx, const float *src, int rows_in, int cols_in,
+                         float *dst, int rows_out, int cols_out);
+/* RectBivariateSpline flow upsampling (src/GenericPyramidalOpticalFlow.py:155-162): interpolating
+ * bicubic (not-a-knot) spline with knots k/n evaluated at i/N, clamped at the last knot, float64,
+ * rounded to float32 and then multiplied by post_scale in float32 (:169-172; pass 1.0f for none). */
+int ofri_spline_upsample(ofri_ctx *ctx, const float *src, int rows_in, int cols_in,
+                         float *dst, int rows_out, int cols_out, float post_scale);
+/* doBiLinearWarping (src/GenericPyramidalOpticalFlow.py:70-116): out = img sampled at (cy, cx),
+ * clamp-to-edge bilinear, float64 weights. */
+int ofri_warp_coords(ofri_ctx *ctx, const float *img, const float *cy, const float *cx,
+                     float *out, int rows, int cols);
+/* the symmetric warp of updateNextPyramidalLevel (:198-201): out = img sampled at
+ * (y + half_sign*V/2, x + half_sign*U/2); half_sign = -1 for image 1, +1 for image 2. */
+int ofri_warp_flow(ofri_ctx *ctx, const float *img, const float *U, const float *V,
+                   float half_sign, float *out, int rows, int cols);
+/* acc += x  (Uaccum += U, src/GenericPyramidalOpticalFlow.py:413-414);  y *= s */
+int ofri_add_inplace(ofri_ctx *ctx, float *acc, const float *x, size_t n);
+int ofri_scale_inplace(ofri_ctx *ctx, float *y, float s, size_t n);
+/* (|a-b|_F) as float64 to the host (b may be NULL: |a|_F); max over a float32 array */
+int ofri_norm_diff(ofri_ctx *ctx, const float *a, const float *b, size_t n, double *out_host);
+int ofri_max(ofri_ctx *ctx, const float *a, size_t n, float *out_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OFRI_H */

@@ -1,0 +1,237 @@
+"""ctypes binding of libofri_hip.so (the C ABI declared in include/ofri.h).
+
+Host-side plumbing only: library loading, error translation, a per-device context and a thin
+device-array handle.  All arithmetic happens in the HIP library; there is no CPU fallback - if the
+library or a GPU is missing, importing works but the first call raises OfriError.
+"""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libofri_hip.so")
+
+
+class OfriError(RuntimeError):
+    pass
+
+
+_lib = None
+_lock = threading.Lock()
+
+_vp, _i, _f, _d, _sz = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t
+_PROTOS = {
+    "ofri_version": ([], _i),
+    "ofri_last_error": ([], C.c_char_p),
+    "ofri_device_count": ([C.POINTER(_i)], _i),
+    "ofri_ctx_create": ([_i, _vp, C.POINTER(_vp)], _i),
+    "ofri_ctx_destroy": ([_vp], _i),
+    "ofri_ctx_sync": ([_vp], _i),
+    "ofri_ctx_stream": ([_vp, C.POINTER(_vp)], _i),
+    "ofri_alloc": ([_vp, _sz, C.POINTER(_vp)], _i),
+    "ofri_free": ([_vp, _vp], _i),
+    "ofri_pool_trim": ([_vp], _i),
+    "ofri_upload": ([_vp, _vp, _vp, _sz], _i),
+    "ofri_download": ([_vp, _vp, _vp, _sz], _i),
+    "ofri_copy": ([_vp, _vp, _vp, _sz], _i),
+    "ofri_zero": ([_vp, _vp, _sz], _i),
+    "ofri_u8_to_f32": ([_vp, _vp, _vp, _sz], _i),
+    "ofri_u16_to_f32": ([_vp, _vp, _vp, _sz], _i),
+    "ofri_event_create": ([_vp, C.POINTER(_vp)], _i),
+    "ofri_event_record": ([_vp, _vp], _i),
+    "ofri_event_elapsed_ms": ([_vp, _vp, C.POINTER(_f)], _i),
+    "ofri_event_destroy": ([_vp], _i),
+    "ofri_gauss_sep": ([_vp, _vp, _vp, _i, _i, _vp, _i], _i),
+    "ofri_gauss_taps": ([_d, _i, _vp], _i),
+    "ofri_hs_derivs": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i], _i),
+    "ofri_hs_iterate": ([_vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i], _i),
+    "ofri_hs_set_fuse": ([_vp, _i], _i),
+    "ofri_prof_enable": ([_vp, _i], _i),
+    "ofri_prof_count": ([_vp, C.POINTER(_i)], _i),
+    "ofri_prof_read": ([_vp, _i, C.POINTER(_f), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)], _i),
+    "ofri_hs_compute": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, C.POINTER(_d)], _i),
+    "ofri_resize_bicubic": ([_vp, _vp, _i, _i, _vp, _i, _i], _i),
+    "ofri_resize_bilinear": ([_vp, _vp, _i, _i, _vp, _i, _i], _i),
+    "ofri_spline_upsample": ([_vp, _vp, _i, _i, _vp, _i, _i, _f], _i),
+    "ofri_warp_coords": ([_vp, _vp, _vp, _vp, _vp, _i, _i], _i),
+    "ofri_warp_flow": ([_vp, _vp, _vp, _vp, _f, _vp, _i, _i], _i),
+    "ofri_add_inplace": ([_vp, _vp, _vp, _sz], _i),
+    "ofri_scale_inplace": ([_vp, _vp, _f, _sz], _i),
+    "ofri_norm_diff": ([_vp, _vp, _vp, _sz, C.POINTER(_d)], _i),
+    "ofri_max": ([_vp, _vp, _sz, C.POINTER(_f)], _i),
+}
+
+
+def lib():
+    """Load libofri_hip.so once; raise OfriError if it has not been built."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise OfriError("HIP library not found at %s - build it with `make -C %s` "
+                                    "(or python -c 'import __graft_entry__ as g; g.build()'); "
+                                    "there is no CPU fallback" % (LIB_PATH, os.path.join(_HERE, "csrc")))
+                l = C.CDLL(LIB_PATH)
+                for name, (args, res) in _PROTOS.items():
+                    fn = getattr(l, name, None)
+                    if fn is None:
+                        continue          # later additions are bound where they are used
+                    fn.argtypes, fn.restype = args, res
+                _lib = l
+    return _lib
+
+
+def bind(name, args, res=_i):
+    """Declare an entry point outside the core table (used by the per-algorithm modules)."""
+    fn = getattr(lib(), name)
+    fn.argtypes, fn.restype = args, res
+    _PROTOS.setdefault(name, (args, res))
+    return fn
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().ofri_last_error()
+        raise OfriError("libofri_hip error %d: %s" % (rc, msg.decode("utf-8", "replace") if msg else "?"))
+
+
+class Context(object):
+    """One GPU, one stream, one memory pool."""
+
+    def __init__(self, device=0, stream=None):
+        self._h = _vp()
+        check(lib().ofri_ctx_create(int(device), _vp(stream) if stream else None, C.byref(self._h)))
+        self.device = int(device)
+
+    @property
+    def handle(self):
+        return self._h
+
+    def sync(self):
+        check(lib().ofri_ctx_sync(self._h))
+
+    def stream(self):
+        s = _vp()
+        check(lib().ofri_ctx_stream(self._h, C.byref(s)))
+        return s.value
+
+    def set_hs_fuse(self, t):
+        check(lib().ofri_hs_set_fuse(self._h, int(t)))
+
+    def prof_enable(self, on=True):
+        check(lib().ofri_prof_enable(self._h, 1 if on else 0))
+
+    def prof_records(self):
+        """[(ms, launches, sweeps, rows, cols)] of the Horn-Schunck sweep loops run since prof_enable."""
+        n = _i(0)
+        check(lib().ofri_prof_count(self._h, C.byref(n)))
+        out = []
+        for k in range(n.value):
+            ms, la, sw, r, c = _f(), _i(), _i(), _i(), _i()
+            check(lib().ofri_prof_read(self._h, k, C.byref(ms), C.byref(la), C.byref(sw), C.byref(r), C.byref(c)))
+            out.append((ms.value, la.value, sw.value, r.value, c.value))
+        return out
+
+    def close(self):
+        if self._h:
+            lib().ofri_ctx_destroy(self._h)
+            self._h = _vp()
+
+    # ---- arrays
+    def empty(self, shape, dtype=np.float32):
+        return DeviceArray(self, shape, dtype)
+
+    def zeros(self, shape, dtype=np.float32):
+        a = DeviceArray(self, shape, dtype)
+        check(lib().ofri_zero(self._h, a.ptr, a.nbytes))
+        return a
+
+    def upload(self, arr, dtype=np.float32):
+        arr = np.ascontiguousarray(arr, dtype=dtype)
+        a = DeviceArray(self, arr.shape, dtype)
+        check(lib().ofri_upload(self._h, a.ptr, arr.ctypes.data, arr.nbytes))
+        return a
+
+    def wrap(self, ptr, shape, dtype=np.float32, keepalive=None):
+        """Adopt external device memory (e.g. a torch tensor's data_ptr()); not freed by us."""
+        return DeviceArray(self, shape, dtype, ptr=ptr, keepalive=keepalive)
+
+    # ---- timing
+    def event(self):
+        e = _vp()
+        check(lib().ofri_event_create(self._h, C.byref(e)))
+        return e
+
+    def record(self, ev):
+        check(lib().ofri_event_record(self._h, ev))
+
+    @staticmethod
+    def elapsed_ms(a, b):
+        ms = _f()
+        check(lib().ofri_event_elapsed_ms(a, b, C.byref(ms)))
+        return ms.value
+
+
+class DeviceArray(object):
+    """A dense row-major array in GPU memory owned by a Context's pool."""
+
+    def __init__(self, ctx, shape, dtype=np.float32, ptr=None, keepalive=None):
+        self.ctx = ctx
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        self._own = ptr is None
+        self._keep = keepalive
+        if ptr is None:
+            p = _vp()
+            check(lib().ofri_alloc(ctx.handle, max(self.nbytes, 1), C.byref(p)))
+            self.ptr = p.value
+        else:
+            self.ptr = int(ptr)
+
+    @property
+    def size(self):
+        return int(np.prod(self.shape))
+
+    def numpy(self):
+        out = np.empty(self.shape, self.dtype)
+        if self.nbytes:
+            check(lib().ofri_download(self.ctx.handle, out.ctypes.data, self.ptr, self.nbytes))
+        return out
+
+    def copy(self):
+        b = DeviceArray(self.ctx, self.shape, self.dtype)
+        check(lib().ofri_copy(self.ctx.handle, b.ptr, self.ptr, self.nbytes))
+        return b
+
+    def __del__(self):
+        try:
+            if self._own and self.ptr and self.ctx._h:
+                lib().ofri_free(self.ctx.handle, self.ptr)
+        except Exception:
+            pass
+        self.ptr = None
+
+
+_contexts = {}
+
+
+def context(device=0):
+    """Process-wide default context of a device (created on first use)."""
+    c = _contexts.get(device)
+    if c is None:
+        c = _contexts[device] = Context(device)
+    return c
+
+
+def device_count():
+    n = _i(0)
+    rc = lib().ofri_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+def as_f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)

@@ -1,0 +1,375 @@
+// Context, pooled device memory, copies, events, small conversions and reductions.
+#include "ofri_internal.h"
+
+static thread_local char g_err[512] = "";
+
+int ofri_set_error(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+extern "C" int ofri_version(void) { return 100; }
+extern "C" const char *ofri_last_error(void) { return g_err; }
+
+extern "C" int ofri_device_count(int *count) {
+    OFRI_REQUIRE(count, "count is null");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return ofri_set_error(OFRI_ENODEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *count = n;
+    return OFRI_OK;
+}
+
+extern "C" int ofri_ctx_create(int device, void *stream, ofri_ctx **out) {
+    OFRI_REQUIRE(out, "out is null");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return ofri_set_error(OFRI_ENODEVICE, "no HIP device available (libofri_hip needs an AMD GPU; there is no CPU fallback)");
+    OFRI_REQUIRE(device >= 0 && device < n, "device %d out of range (0..%d)", device, n - 1);
+    OFRI_HIP(hipSetDevice(device));
+    ofri_ctx *c = new ofri_ctx();
+    c->device = device;
+    if (stream) {
+        c->stream = (hipStream_t)stream;
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete c; return ofri_set_error(OFRI_EHIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+        c->owns_stream = true;
+    }
+    hipError_t e = hipHostMalloc(&c->pinned, 4096, hipHostMallocDefault);
+    if (e != hipSuccess) { delete c; return ofri_set_error(OFRI_EHIP, "hipHostMalloc: %s", hipGetErrorString(e)); }
+    *out = c;
+    return OFRI_OK;
+}
+
+extern "C" int ofri_pool_trim(ofri_ctx *ctx) {
+    OFRI_TRY(ofri_check_ctx(ctx));
+    OFRI_HIP(hipStreamSynchronize(ctx->stream));
+    for (auto &kv : ctx->pool)
+        for (void *p : kv.second) (void)hipFree(p);
+    ctx->pool.clear();
+    return OFRI_OK;
+}
+
+extern "C" int ofri_ctx_destroy(ofri_ctx *ctx) {
+    if (!ctx) return OFRI_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &kv : ctx->pool)
+        for (void *p : kv.second) (void)hipFree(p);
+    for (auto &kv : ctx->live) (void)hipFree(kv.first);
+    for (auto &r : ctx->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto &kv : ctx->tables) (void)hipFree(kv.second);
+    if (ctx->red_partials) (void)hipFree(ctx->red_partials);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return OFRI_OK;
+}
+
+extern "C" int ofri_ctx_sync(ofri_ctx *ctx) {
+    OFRI_TRY(ofri_check_ctx(ctx));
+    OFRI_HIP(hipStreamSynchronize(ctx->stream));
+    return OFRI_OK;
+}
+
+extern "C" int ofri_ctx_stream(ofri_ctx *ctx, void **stream) {
+    OFRI_REQUIRE(ctx && stream, "null argument");
+    *stream = (void *)ctx->stream;
+    return OFRI_OK;
+}
+
+static size_t round_block(size_t bytes) {
+    const size_t g = bytes <= (1u << 20) ? 4096 : (size_t)(2u << 20);   // small: 4 KiB, large: 2 MiB granules
+    return (bytes + g - 1) / g * g;
+}
+
+extern "C" int ofri_alloc(ofri_ctx *ctx, size_t bytes, void **dptr) {
+    OFRI_TRY(ofri_check_ctx(ctx));
+    OFRI_REQUIRE(dptr, "dptr is null");
+    *dptr = nullptr;
+    OFRI_REQUIRE(bytes > 0, "zero-byte allocation");
+    size_t rb = round_block(bytes);
+    auto it = ctx->pool.find(rb);
+    void *p = nullptr;
+    if (it != ctx->pool.end() && !it->second.empty()) {
+        p = it->second.back();
+        it->second.pop_back();
+    } else {
+        hipError_t e = hipMalloc(&p, rb);
+        if (e != hipSuccess) {
+            // release cached blocks and retry once
+            (void)ofri_pool_trim(ctx);
+            e = hipMalloc(&p, rb);
+            if (e != hipSuccess) return ofri_set_error(OFRI_ENOMEM, "hipMalloc(%zu): %s", rb, hipGetErrorString(e));
+        }
+    }
+    ctx->live[p] = rb;
+    *dptr = p;
+    return OFRI_OK;
+}
+
+extern "C" int ofri_free(ofri_ctx *ctx, void *dptr) {
+    if (!dptr) return OFRI_OK;
+    OFRI_REQUIRE(ctx, "null context");
+    auto it = ctx->live.find(dptr);
+    OFRI_REQUIRE(it != ctx->live.end(), "pointer %p was not allocated by this context", dptr);
+    // stream-ordered reuse: every consumer of the pool enqueues on ctx->stream, so a block handed
+    // out again is only touched after the work that last used it
+    ctx->pool[it->second].push_back(dptr);
+    ctx->live.erase(it);
+    return OFRI_OK;
+}
+
+extern "C" int ofri_upload(ofri_ctx *ctx, void *dst, const void *src_host, size_t bytes) {
+    OFRI_TRY(ofri_check_ctx(ctx));
+    OFRI_REQUIRE(dst && src_host, "null pointer");
+    if (!bytes) return OFRI_OK;
+    OFRI_HIP(hipMemcpyAsync(dst, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    OFRI_HIP(hipStreamSynchronize(ctx->stream));
+    return OFRI_OK;
+}
+
+extern "C" int ofri_download(ofri_ctx *ctx, void *dst_host, const void *src, size_t bytes) {
+    OFRI_TRY(ofri_check_ctx(ctx));
+    OFRI_REQUIRE(dst_host && src, "null pointer");
+    if (!bytes) return OFRI_OK;
+    OFRI_HIP(hipMemcpyAsync(dst_host, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    OFRI_HIP(hipStreamSynchronize(ctx->stream));
+    return OFRI_OK;
+}
+
+extern "C" int ofri_copy(ofri_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    OFRI_TRY(ofri_check_ctx(ctx));
+    OFRI_REQUIRE(dst && src, "null pointer");
+    if (!bytes) return OFRI_OK;
+    OFRI_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return OFRI_OK;
+}
+
+extern "C" int ofri_zero(ofri_ctx *ctx, void *dst, size_t bytes) {
+    OFRI_TRY(ofri_check_ctx(ctx));
+    OFRI_REQUIRE(dst, "null pointer");
+    if (!bytes) return OFRI_OK;
+    OFRI_HIP(hipMemsetAsync(dst, 0, bytes, ctx->stream));
+    return OFRI_OK;
+}
+
+int ofri_upload_table(ofri_ctx *ctx, PoolBuf &buf, const void *host, size_t bytes) {
+    OFRI_TRY(buf.get(bytes));
+    OFRI_HIP(hipMemcpyAsync(buf.p, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return OFRI_OK;
+}
+
+int ofri_cached_table(ofri_ctx *ctx, const std::string &key, const void *host, size_t bytes, void **dptr) {
+    void *p = ofri_find_table(ctx, key);
+    if (!p) {
+        OFRI_HIP(hipMalloc(&p, bytes));
+        hipError_t e = hipMemcpy(p, host, bytes, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipFree(p); return ofri_set_error(OFRI_EHIP, "table upload: %s", hipGetErrorString(e)); }
+        ctx->tables[key] = p;
+    }
+    *dptr = p;
+    return OFRI_OK;
+}
+
+// ---- events ------------------------------------------------------------------------------------
+extern "C" int ofri_event_create(ofri_ctx *ctx, ofri_event **ev) {
+    OFRI_TRY(ofri_check_ctx(ctx));
+    OFRI_REQUIRE(ev, "ev is null");
+    ofri_event *e = new ofri_event();
+    e->device = ctx->device;
+    hipError_t r = hipEventCreate(&e->ev);
+    if (r != hipSuccess) { delete e; return ofri_set_error(OFRI_EHIP, "hipEventCreate: %s", hipGetErrorString(r)); }
+    *ev = e;
+    return OFRI_OK;
+}
+extern "C" int ofri_event_record(ofri_ctx *ctx, ofri_event *ev) {
+    OFRI_TRY(ofri_check_ctx(ctx));
+    OFRI_REQUIRE(ev, "ev is null");
+    OFRI_HIP(hipEventRecord(ev->ev, ctx->stream));
+    return OFRI_OK;
+}
+extern "C" int ofri_event_elapsed_ms(ofri_event *start, ofri_event *stop, float *ms) {
+    OFRI_REQUIRE(start && stop && ms, "null argument");
+    OFRI_HIP(hipSetDevice(stop->device));
+    OFRI_HIP(hipEventSynchronize(stop->ev));
+    OFRI_HIP(hipEventElapsedTime(ms, start->ev, stop->ev));
+    return OFRI_OK;
+}
+extern "C" int ofri_event_destroy(ofri_event *ev) {
+    if (!ev) return OFRI_OK;
+    (void)hipSetDevice(ev->device);
+    (void)hipEventDestroy(ev->ev);
+    delete ev;
+    return OFRI_OK;
+}
+
+// ---- element-wise helpers ------------------------------------------------------------------------
+template <class T>
+__global__ void k_to_f32(const T *__restrict__ s, float *__restrict__ d, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, st = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += st) d[i] = (float)s[i];
+}
+static int grid_for(size_t n, int block) {
+    size_t g = (n + block - 1) / block;
+    return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+extern "C" int ofri_u8_to_f32(ofri_ctx *ctx, const unsigned char *src, float *dst, size_t n) {
+    OFRI_TRY(ofri_check_ctx(ctx));
+    OFRI_REQUIRE(src && dst, "null pointer");
+    if (!n) return OFRI_OK;
+    k_to_f32<unsigned char><<<grid_for(n, 256), 256, 0, ctx->stream>>>(src, dst, n);
+    OFRI_LAUNCH_CHECK();
+    return OFRI_OK;
+}
+extern "C" int ofri_u16_to_f32(ofri_ctx *ctx, const unsigned short *src, float *dst, size_t n) {
+    OFRI_TRY(ofri_check_ctx(ctx));
+    OFRI_REQUIRE(src && dst, "null pointer");
+    if (!n) return OFRI_OK;
+    k_to_f32<unsigned short><<<grid_for(n, 256), 256, 0, ctx->stream>>>(src, dst, n);
+    OFRI_LAUNCH_CHECK();
+    return OFRI_OK;
+}
+
+__global__ void k_add_inplace(float *__restrict__ acc, const float *__restrict__ x, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, st = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += st) acc[i] = acc[i] + x[i];
+}
+__global__ void k_scale_inplace(float *__restrict__ y, float s, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, st = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += st) y[i] = y[i] * s;
+}
+extern "C" int ofri_add_inplace(ofri_ctx *ctx, float *acc, const float *x, size_t n) {
+    OFRI_TRY(ofri_check_ctx(ctx));
+    OFRI_REQUIRE(acc && x, "null pointer");
+    if (!n) return OFRI_OK;
+    k_add_inplace<<<grid_for(n, 256), 256, 0, ctx->stream>>>(acc, x, n);
+    OFRI_LAUNCH_CHECK();
+    return OFRI_OK;
+}
+extern "C" int ofri_scale_inplace(ofri_ctx *ctx, float *y, float s, size_t n) {
+    OFRI_TRY(ofri_check_ctx(ctx));
+    OFRI_REQUIRE(y, "null pointer");
+    if (!n) return OFRI_OK;
+    k_scale_inplace<<<grid_for(n, 256), 256, 0, ctx->stream>>>(y, s, n);
+    OFRI_LAUNCH_CHECK();
+    return OFRI_OK;
+}
+
+// ---- reductions ----------------------------------------------------------------------------------
+// Two-stage, fixed-shape tree (no atomics) so results are reproducible run to run.
+#define RED_BLOCKS 1024
+__device__ inline double wave_sum(double v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ inline float wave_max(float v) {
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_down(v, o, 64));
+    return v;
+}
+__global__ void k_sqdiff_partial(const float *__restrict__ a, const float *__restrict__ b, size_t n, double *__restrict__ part) {
+    __shared__ double sm[4];
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, st = (size_t)gridDim.x * blockDim.x;
+    double s = 0.0;
+    for (; i < n; i += st) {
+        double d = b ? (double)a[i] - (double)b[i] : (double)a[i];
+        s += d * d;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+__global__ void k_sum_final(const double *__restrict__ part, int n, double *__restrict__ out, int take_sqrt) {
+    __shared__ double sm[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s += part[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = sm[0] + sm[1] + sm[2] + sm[3];
+        out[0] = take_sqrt ? sqrt(t) : t;
+    }
+}
+__global__ void k_max_partial(const float *__restrict__ a, size_t n, double *__restrict__ part) {
+    __shared__ float sm[4];
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, st = (size_t)gridDim.x * blockDim.x;
+    float m = -INFINITY;
+    for (; i < n; i += st) m = fmaxf(m, a[i]);
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (double)fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+}
+__global__ void k_max_final(const double *__restrict__ part, int n, double *__restrict__ out) {
+    __shared__ float sm[4];
+    float m = -INFINITY;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) m = fmaxf(m, (float)part[i]);
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (double)fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+}
+
+static int ensure_red(ofri_ctx *ctx) {
+    if (!ctx->red_partials) {
+        OFRI_HIP(hipMalloc((void **)&ctx->red_partials, (RED_BLOCKS + 64) * sizeof(double)));
+        ctx->red_capacity = RED_BLOCKS + 64;
+    }
+    return OFRI_OK;
+}
+
+// device-side |a-b|_F into slot `slot` (0..63) of the context's result area; no host sync
+int ofri_norm_diff_dev(ofri_ctx *ctx, const float *a, const float *b, size_t n, int slot) {
+    OFRI_TRY(ensure_red(ctx));
+    int g = grid_for(n, 256);
+    if (g > RED_BLOCKS) g = RED_BLOCKS;
+    k_sqdiff_partial<<<g, 256, 0, ctx->stream>>>(a, b, n, ctx->red_partials);
+    OFRI_LAUNCH_CHECK();
+    k_sum_final<<<1, 256, 0, ctx->stream>>>(ctx->red_partials, g, ctx->red_partials + RED_BLOCKS + slot, 1);
+    OFRI_LAUNCH_CHECK();
+    return OFRI_OK;
+}
+int ofri_max_dev(ofri_ctx *ctx, const float *a, size_t n, int slot) {
+    OFRI_TRY(ensure_red(ctx));
+    int g = grid_for(n, 256);
+    if (g > RED_BLOCKS) g = RED_BLOCKS;
+    k_max_partial<<<g, 256, 0, ctx->stream>>>(a, n, ctx->red_partials);
+    OFRI_LAUNCH_CHECK();
+    k_max_final<<<1, 256, 0, ctx->stream>>>(ctx->red_partials, g, ctx->red_partials + RED_BLOCKS + slot);
+    OFRI_LAUNCH_CHECK();
+    return OFRI_OK;
+}
+double *ofri_red_slot(ofri_ctx *ctx, int slot) { return ctx->red_partials + RED_BLOCKS + slot; }
+int ofri_read_slots(ofri_ctx *ctx, int first, int count, double *out_host) {
+    OFRI_HIP(hipMemcpyAsync(ctx->pinned, ofri_red_slot(ctx, first), count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    OFRI_HIP(hipStreamSynchronize(ctx->stream));
+    memcpy(out_host, ctx->pinned, count * sizeof(double));
+    return OFRI_OK;
+}
+
+extern "C" int ofri_norm_diff(ofri_ctx *ctx, const float *a, const float *b, size_t n, double *out_host) {
+    OFRI_TRY(ofri_check_ctx(ctx));
+    OFRI_REQUIRE(a && out_host, "null pointer");
+    if (!n) { *out_host = 0.0; return OFRI_OK; }
+    OFRI_TRY(ofri_norm_diff_dev(ctx, a, b, n, 0));
+    return ofri_read_slots(ctx, 0, 1, out_host);
+}
+extern "C" int ofri_max(ofri_ctx *ctx, const float *a, size_t n, float *out_host) {
+    OFRI_TRY(ofri_check_ctx(ctx));
+    OFRI_REQUIRE(a && out_host && n > 0, "null pointer or empty array");
+    OFRI_TRY(ofri_max_dev(ctx, a, n, 0));
+    double d;
+    OFRI_TRY(ofri_read_slots(ctx, 0, 1, &d));
+    *out_host = (float)d;
+    return OFRI_OK;
+}

@@ -1,0 +1,266 @@
+// Horn-Schunck: derivative cube, Jacobi sweeps, error norm.
+// Reference behaviour: src/HornSchunck.py:52-127 (HS_helper2, HS_helper, HS, computeDerivatives).
+#include "ofri_internal.h"
+
+int ofri_norm_diff_dev(ofri_ctx *ctx, const float *a, const float *b, size_t n, int slot);
+int ofri_read_slots(ofri_ctx *ctx, int first, int count, double *out_host);
+
+// ---------------------------------------------------------------------------------------------
+// Derivatives.  scipy.ndimage.convolve with a 2x2 kernel w and 'mirror' border evaluates
+//   out[i,j] = w11*in[i,j] + w10*in[i,j+1] + w01*in[i+1,j] + w00*in[i+1,j+1]
+// in float64 and rounds to float32; the reference then adds the two images' results in float32.
+// All weights are +-0.25, so a float64 sum of the four taps scaled by 0.25 reproduces it exactly.
+__global__ void k_hs_derivs(const float *__restrict__ P, const float *__restrict__ Q,   // P = first, Q = second
+                            float *__restrict__ fx, float *__restrict__ fy, float *__restrict__ ft,
+                            int H, int W) {
+    int x = blockIdx.x * blockDim.x + threadIdx.x;
+    int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= W || y >= H) return;
+    int x1 = refl101(x + 1, W), y1 = refl101(y + 1, H);
+    size_t r0 = (size_t)y * W, r1 = (size_t)y1 * W;
+    double p00 = P[r0 + x], p01 = P[r0 + x1], p10 = P[r1 + x], p11 = P[r1 + x1];
+    double q00 = Q[r0 + x], q01 = Q[r0 + x1], q10 = Q[r1 + x], q11 = Q[r1 + x1];
+    float pfx = (float)(0.25 * (((p00 - p01) + p10) - p11));
+    float qfx = (float)(0.25 * (((q00 - q01) + q10) - q11));
+    float pfy = (float)(0.25 * (((p00 + p01) - p10) - p11));
+    float qfy = (float)(0.25 * (((q00 + q01) - q10) - q11));
+    float qft = (float)(0.25 * (((q00 + q01) + q10) + q11));
+    float pft = (float)(-0.25 * (((p00 + p01) + p10) + p11));
+    size_t o = r0 + x;
+    fx[o] = __fadd_rn(pfx, qfx);
+    fy[o] = __fadd_rn(pfy, qfy);
+    ft[o] = __fadd_rn(qft, pft);
+}
+
+extern "C" int ofri_hs_derivs(ofri_ctx *ctx, const float *first, const float *second,
+                              float *fx, float *fy, float *ft, int rows, int cols) {
+    OFRI_TRY(ofri_check_ctx(ctx));
+    OFRI_REQUIRE(first && second && fx && fy && ft, "null pointer");
+    OFRI_REQUIRE(rows > 0 && cols > 0, "bad shape %d x %d", rows, cols);
+    dim3 b(64, 4), g(ceil_div(cols, 64), ceil_div(rows, 4));
+    k_hs_derivs<<<g, b, 0, ctx->stream>>>(first, second, fx, fy, ft, rows, cols);
+    OFRI_LAUNCH_CHECK();
+    return OFRI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Jacobi sweep, one launch per sweep.
+//   ubar = K*U, vbar = K*V  (K = [[1/12,1/6,1/12],[1/6,0,1/6],[1/12,1/6,1/12]] in float32, 'mirror')
+//   der  = (fx*ubar + fy*vbar + ft) / (alpha^2 + fx^2 + fy^2);  U = ubar - fx*der;  V = vbar - fy*der
+// EXACT = true follows scipy's float64 tap-by-tap accumulation and NumPy's unfused float32 element
+// ops, so the result is bit-identical to the reference; EXACT = false is plain float32 with FMAs.
+#define W6  0.16666667163372040   // float32(1/6)  as a double
+#define W12 0.08333333581686020   // float32(1/12) as a double
+
+template <bool EXACT>
+__device__ __forceinline__ float avg9(float a00, float a01, float a02, float a10, float a12,
+                                      float a20, float a21, float a22) {
+    if (EXACT) {
+        double t = __dmul_rn((double)a00, W12);
+        t = __dadd_rn(t, __dmul_rn((double)a01, W6));
+        t = __dadd_rn(t, __dmul_rn((double)a02, W12));
+        t = __dadd_rn(t, __dmul_rn((double)a10, W6));
+        t = __dadd_rn(t, __dmul_rn((double)a12, W6));
+        t = __dadd_rn(t, __dmul_rn((double)a20, W12));
+        t = __dadd_rn(t, __dmul_rn((double)a21, W6));
+        t = __dadd_rn(t, __dmul_rn((double)a22, W12));
+        return (float)t;
+    } else {
+        return ((a01 + a21) + (a10 + a12)) * (float)W6 + ((a00 + a02) + (a20 + a22)) * (float)W12;
+    }
+}
+
+template <bool EXACT>
+__device__ __forceinline__ void hs_point(float ua, float va, float fx, float fy, float ft, float a2,
+                                         float &un, float &vn) {
+    if (EXACT) {
+        float den = __fadd_rn(__fadd_rn(a2, __fmul_rn(fx, fx)), __fmul_rn(fy, fy));
+        float num = __fadd_rn(__fadd_rn(__fmul_rn(fx, ua), __fmul_rn(fy, va)), ft);
+        float der = __fdiv_rn(num, den);
+        un = __fsub_rn(ua, __fmul_rn(fx, der));
+        vn = __fsub_rn(va, __fmul_rn(fy, der));
+    } else {
+        float den = a2 + fx * fx + fy * fy;
+        float der = (fx * ua + fy * va + ft) / den;
+        un = ua - fx * der;
+        vn = va - fy * der;
+    }
+}
+
+// any shape: one pixel per thread
+template <bool EXACT>
+__global__ void k_hs_sweep_scalar(const float *__restrict__ U, const float *__restrict__ V,
+                                  const float *__restrict__ fx, const float *__restrict__ fy,
+                                  const float *__restrict__ ft, float *__restrict__ Un,
+                                  float *__restrict__ Vn, float a2, int H, int W) {
+    int x = blockIdx.x * blockDim.x + threadIdx.x;
+    int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= W || y >= H) return;
+    int xm = refl101(x - 1, W), xp = refl101(x + 1, W);
+    size_t rm = (size_t)refl101(y - 1, H) * W, rc = (size_t)y * W, rp = (size_t)refl101(y + 1, H) * W;
+    float ua = avg9<EXACT>(U[rm + xm], U[rm + x], U[rm + xp], U[rc + xm], U[rc + xp], U[rp + xm], U[rp + x], U[rp + xp]);
+    float va = avg9<EXACT>(V[rm + xm], V[rm + x], V[rm + xp], V[rc + xm], V[rc + xp], V[rp + xm], V[rp + x], V[rp + xp]);
+    float un, vn;
+    hs_point<EXACT>(ua, va, fx[rc + x], fy[rc + x], ft[rc + x], a2, un, vn);
+    Un[rc + x] = un;
+    Vn[rc + x] = vn;
+}
+
+// cols % 4 == 0: each thread owns 4 adjacent pixels of RPT consecutive rows and slides a 3-row window
+// of U and V through registers, so each U/V row is fetched once per thread (16-byte loads).
+#define HS_RPT 4
+template <bool EXACT>
+__global__ void __launch_bounds__(256)
+k_hs_sweep_vec4(const float *__restrict__ U, const float *__restrict__ V,
+                const float *__restrict__ fx, const float *__restrict__ fy,
+                const float *__restrict__ ft, float *__restrict__ Un, float *__restrict__ Vn,
+                float a2, int H, int W) {
+    int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    int y0 = (blockIdx.y * blockDim.y + threadIdx.y) * HS_RPT;
+    if (x0 >= W || y0 >= H) return;
+    int xl = refl101(x0 - 1, W), xr = refl101(x0 + 4, W);
+    float u[3][6], v[3][6];
+    auto load_row = [&](int slot, int y) {
+        size_t r = (size_t)refl101(y, H) * W;
+        float4 a = *reinterpret_cast<const float4 *>(U + r + x0);
+        float4 b = *reinterpret_cast<const float4 *>(V + r + x0);
+        u[slot][0] = U[r + xl]; u[slot][1] = a.x; u[slot][2] = a.y; u[slot][3] = a.z; u[slot][4] = a.w; u[slot][5] = U[r + xr];
+        v[slot][0] = V[r + xl]; v[slot][1] = b.x; v[slot][2] = b.y; v[slot][3] = b.z; v[slot][4] = b.w; v[slot][5] = V[r + xr];
+    };
+    load_row(0, y0 - 1);
+    load_row(1, y0);
+#pragma unroll
+    for (int r = 0; r < HS_RPT; ++r) {
+        int y = y0 + r;
+        if (y >= H) break;
+        const int m = r % 3, c = (r + 1) % 3, p = (r + 2) % 3;
+        load_row(p, y + 1);
+        size_t o = (size_t)y * W + x0;
+        float4 gx = *reinterpret_cast<const float4 *>(fx + o);
+        float4 gy = *reinterpret_cast<const float4 *>(fy + o);
+        float4 gt = *reinterpret_cast<const float4 *>(ft + o);
+        float gxa[4] = {gx.x, gx.y, gx.z, gx.w}, gya[4] = {gy.x, gy.y, gy.z, gy.w}, gta[4] = {gt.x, gt.y, gt.z, gt.w};
+        float ou[4], ov[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float ua = avg9<EXACT>(u[m][k], u[m][k + 1], u[m][k + 2], u[c][k], u[c][k + 2], u[p][k], u[p][k + 1], u[p][k + 2]);
+            float va = avg9<EXACT>(v[m][k], v[m][k + 1], v[m][k + 2], v[c][k], v[c][k + 2], v[p][k], v[p][k + 1], v[p][k + 2]);
+            hs_point<EXACT>(ua, va, gxa[k], gya[k], gta[k], a2, ou[k], ov[k]);
+        }
+        *reinterpret_cast<float4 *>(Un + o) = make_float4(ou[0], ou[1], ou[2], ou[3]);
+        *reinterpret_cast<float4 *>(Vn + o) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+    }
+}
+
+template <bool EXACT>
+static int hs_sweep_launch(ofri_ctx *ctx, const float *U, const float *V, const float *fx, const float *fy,
+                           const float *ft, float *Un, float *Vn, float a2, int H, int W) {
+    bool aligned = ((((size_t)U | (size_t)V | (size_t)fx | (size_t)fy | (size_t)ft | (size_t)Un | (size_t)Vn) & 15) == 0);
+    if (W % 4 == 0 && aligned && W >= 8) {
+        dim3 b(64, 4), g(ceil_div(W, 256), ceil_div(H, 4 * HS_RPT));
+        k_hs_sweep_vec4<EXACT><<<g, b, 0, ctx->stream>>>(U, V, fx, fy, ft, Un, Vn, a2, H, W);
+    } else {
+        dim3 b(64, 4), g(ceil_div(W, 64), ceil_div(H, 4));
+        k_hs_sweep_scalar<EXACT><<<g, b, 0, ctx->stream>>>(U, V, fx, fy, ft, Un, Vn, a2, H, W);
+    }
+    OFRI_LAUNCH_CHECK();
+    return OFRI_OK;
+}
+
+int ofri_hs_fused_passes(ofri_ctx *ctx, float *&cu, float *&cv, float *&nu, float *&nv, const float *fx,
+                         const float *fy, const float *ft, float a2, int &remaining, int &launches, int H, int W);
+
+extern "C" int ofri_hs_set_fuse(ofri_ctx *ctx, int sweeps_per_launch) {
+    OFRI_REQUIRE(ctx, "null context");
+    OFRI_REQUIRE(sweeps_per_launch >= -1 && sweeps_per_launch <= 64, "sweeps_per_launch out of range");
+    ctx->hs_fuse = sweeps_per_launch;
+    return OFRI_OK;
+}
+
+extern "C" int ofri_hs_iterate(ofri_ctx *ctx, float *U, float *V, const float *fx, const float *fy,
+                               const float *ft, float alpha, int niter, int rows, int cols) {
+    OFRI_TRY(ofri_check_ctx(ctx));
+    OFRI_REQUIRE(U && V && fx && fy && ft, "null pointer");
+    OFRI_REQUIRE(rows > 0 && cols > 0, "bad shape %d x %d", rows, cols);
+    OFRI_REQUIRE(niter >= 0, "niter < 0");
+    if (niter == 0) return OFRI_OK;
+    size_t bytes = (size_t)rows * cols * sizeof(float);
+    PoolBuf tu(ctx), tv(ctx);
+    OFRI_TRY(tu.get(bytes));
+    OFRI_TRY(tv.get(bytes));
+    float a2 = alpha * alpha;            // alpha is a float32 in the reference's compiled signature
+    float *cu = U, *cv = V, *nu = tu.as<float>(), *nv = tv.as<float>();
+    int remaining = niter, launches = 0;
+    ofri_ctx::ProfRec rec{};
+    if (ctx->prof) {
+        OFRI_HIP(hipEventCreate(&rec.a)); OFRI_HIP(hipEventCreate(&rec.b));
+        OFRI_HIP(hipEventRecord(rec.a, ctx->stream));
+    }
+    const bool exact = ctx->hs_fuse == -1;  // -1: bit-exact restatement of scipy's float64 accumulation
+    if (!exact && ctx->hs_fuse != 1)
+        OFRI_TRY(ofri_hs_fused_passes(ctx, cu, cv, nu, nv, fx, fy, ft, a2, remaining, launches, rows, cols));
+    for (; remaining > 0; --remaining, ++launches) {
+        if (exact) OFRI_TRY(hs_sweep_launch<true>(ctx, cu, cv, fx, fy, ft, nu, nv, a2, rows, cols));
+        else       OFRI_TRY(hs_sweep_launch<false>(ctx, cu, cv, fx, fy, ft, nu, nv, a2, rows, cols));
+        float *t = cu; cu = nu; nu = t;
+        t = cv; cv = nv; nv = t;
+    }
+    if (ctx->prof) {
+        OFRI_HIP(hipEventRecord(rec.b, ctx->stream));
+        rec.rows = rows; rec.cols = cols; rec.launches = launches; rec.sweeps = niter;
+        ctx->prof_recs.push_back(rec);
+    }
+    if (cu != U) {
+        OFRI_HIP(hipMemcpyAsync(U, cu, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+        OFRI_HIP(hipMemcpyAsync(V, cv, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    return OFRI_OK;
+}
+
+extern "C" int ofri_hs_compute(ofri_ctx *ctx, const float *frame0, const float *frame1,
+                               const float *U_in, const float *V_in, float *U_out, float *V_out,
+                               float alpha, int niter, int rows, int cols, double *err_host) {
+    OFRI_TRY(ofri_check_ctx(ctx));
+    OFRI_REQUIRE(frame0 && frame1 && U_in && V_in && U_out && V_out, "null pointer");
+    OFRI_REQUIRE(U_out != U_in && V_out != V_in && U_out != V_out, "output must not alias input");
+    OFRI_REQUIRE(rows > 0 && cols > 0 && niter >= 0, "bad shape or niter");
+    size_t n = (size_t)rows * cols, bytes = n * sizeof(float);
+    PoolBuf fx(ctx), fy(ctx), ft(ctx);
+    OFRI_TRY(fx.get(bytes)); OFRI_TRY(fy.get(bytes)); OFRI_TRY(ft.get(bytes));
+    // HS(im2=frame0, im1=frame1) -> computeDerivatives(im1=frame1, im2=frame0)   (HornSchunck.py:37,73,84)
+    OFRI_TRY(ofri_hs_derivs(ctx, frame1, frame0, fx.as<float>(), fy.as<float>(), ft.as<float>(), rows, cols));
+    OFRI_HIP(hipMemcpyAsync(U_out, U_in, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    OFRI_HIP(hipMemcpyAsync(V_out, V_in, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    OFRI_TRY(ofri_hs_iterate(ctx, U_out, V_out, fx.as<float>(), fy.as<float>(), ft.as<float>(), alpha, niter, rows, cols));
+    if (err_host) {
+        OFRI_TRY(ofri_norm_diff_dev(ctx, U_out, U_in, n, 0));
+        OFRI_TRY(ofri_norm_diff_dev(ctx, V_out, V_in, n, 1));
+        double r[2];
+        OFRI_TRY(ofri_read_slots(ctx, 0, 2, r));
+        *err_host = (r[0] + r[1]) / ((double)rows * (double)cols);
+    }
+    return OFRI_OK;
+}
+
+extern "C" int ofri_prof_enable(ofri_ctx *ctx, int on) {
+    OFRI_TRY(ofri_check_ctx(ctx));
+    for (auto &r : ctx->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    ctx->prof_recs.clear();
+    ctx->prof = on != 0;
+    return OFRI_OK;
+}
+extern "C" int ofri_prof_count(ofri_ctx *ctx, int *count) {
+    OFRI_REQUIRE(ctx && count, "null argument");
+    *count = (int)ctx->prof_recs.size();
+    return OFRI_OK;
+}
+extern "C" int ofri_prof_read(ofri_ctx *ctx, int idx, float *ms, int *launches, int *sweeps, int *rows, int *cols) {
+    OFRI_TRY(ofri_check_ctx(ctx));
+    OFRI_REQUIRE(idx >= 0 && idx < (int)ctx->prof_recs.size(), "record index out of range");
+    OFRI_REQUIRE(ms && launches && sweeps && rows && cols, "null argument");
+    auto &r = ctx->prof_recs[idx];
+    OFRI_HIP(hipEventSynchronize(r.b));
+    OFRI_HIP(hipEventElapsedTime(ms, r.a, r.b));
+    *launches = r.launches; *sweeps = r.sweeps; *rows = r.rows; *cols = r.cols;
+    return OFRI_OK;
+}

@@ -1,0 +1,107 @@
+// Internal declarations shared by the HIP translation units of libofri_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <mutex>
+#include <vector>
+#include "../../include/ofri.h"
+
+struct ofri_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    int hs_fuse = 0;                                   // sweeps per launch, 0 = automatic
+    std::map<size_t, std::vector<void *>> pool;        // free blocks by rounded size
+    std::map<void *, size_t> live;                     // blocks handed out -> rounded size
+    double *red_partials = nullptr;                    // device scratch for two-stage reductions
+    size_t red_capacity = 0;
+    std::map<std::string, void *> tables;              // cached device-resident constant tables
+    void *pinned = nullptr;                            // 4 KiB pinned host buffer for scalar read-back
+    // optional timing of the Horn-Schunck sweep launches (ofri_prof_enable)
+    bool prof = false;
+    struct ProfRec { hipEvent_t a, b; int rows, cols, launches, sweeps; };
+    std::vector<ProfRec> prof_recs;
+};
+
+struct ofri_event {
+    hipEvent_t ev;
+    int device;
+};
+
+int ofri_set_error(int code, const char *fmt, ...);
+
+#define OFRI_HIP(call)                                                                     \
+    do {                                                                                   \
+        hipError_t e_ = (call);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return ofri_set_error(OFRI_EHIP, "%s failed: %s (%s:%d)", #call,               \
+                                  hipGetErrorString(e_), __FILE__, __LINE__);              \
+    } while (0)
+
+#define OFRI_REQUIRE(cond, ...)                                                            \
+    do {                                                                                   \
+        if (!(cond)) return ofri_set_error(OFRI_EINVAL, __VA_ARGS__);                      \
+    } while (0)
+
+#define OFRI_TRY(expr)                                                                     \
+    do {                                                                                   \
+        int r_ = (expr);                                                                   \
+        if (r_ != OFRI_OK) return r_;                                                      \
+    } while (0)
+
+// kernel launch check: launch errors surface through hipGetLastError
+#define OFRI_LAUNCH_CHECK()                                                                \
+    do {                                                                                   \
+        hipError_t e_ = hipGetLastError();                                                 \
+        if (e_ != hipSuccess)                                                              \
+            return ofri_set_error(OFRI_EHIP, "kernel launch failed: %s (%s:%d)",           \
+                                  hipGetErrorString(e_), __FILE__, __LINE__);              \
+    } while (0)
+
+static inline int ofri_check_ctx(ofri_ctx *ctx) {
+    if (!ctx) return ofri_set_error(OFRI_EINVAL, "null context");
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e != hipSuccess) return ofri_set_error(OFRI_EHIP, "hipSetDevice(%d): %s", ctx->device, hipGetErrorString(e));
+    return OFRI_OK;
+}
+
+// RAII block from the context pool (returned to the pool, not to the driver)
+struct PoolBuf {
+    ofri_ctx *ctx;
+    void *p = nullptr;
+    PoolBuf(ofri_ctx *c) : ctx(c) {}
+    int get(size_t bytes) { return ofri_alloc(ctx, bytes, &p); }
+    ~PoolBuf() { if (p) ofri_free(ctx, p); }
+    template <class T> T *as() { return static_cast<T *>(p); }
+};
+
+// upload a small host table into a pooled device block (stream-ordered; the host copy is staged
+// before returning because pageable hipMemcpyAsync completes its host read before it returns)
+int ofri_upload_table(ofri_ctx *ctx, PoolBuf &buf, const void *host, size_t bytes);
+// device copy of a host table, built once per (context, key) and kept until the context dies
+int ofri_cached_table(ofri_ctx *ctx, const std::string &key, const void *host, size_t bytes, void **dptr);
+static inline void *ofri_find_table(ofri_ctx *ctx, const std::string &key) {
+    auto it = ctx->tables.find(key);
+    return it == ctx->tables.end() ? nullptr : it->second;
+}
+
+static inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// reflect-101 ("mirror", edge sample not repeated): -1 -> 1, n -> n-2; valid for |overshoot| <= n-1
+__host__ __device__ static inline int refl101(int i, int n) {
+    if (n == 1) return 0;
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * n - 2 - i;
+    return i;
+}
+// symmetric reflect (edge sample repeated): -1 -> 0, n -> n-1
+__host__ __device__ static inline int reflsym(int i, int n) {
+    if (i < 0) i = -i - 1;
+    if (i >= n) i = 2 * n - 1 - i;
+    return i;
+}
+__host__ __device__ static inline int clampi(int i, int lo, int hi) { return i < lo ? lo : (i > hi ? hi : i); }

@@ -1,0 +1,72 @@
+"""CPU-side checks of the boundary: the library loads, exports what include/ofri.h declares, reports
+errors as codes + messages, and the host-only helpers agree with the oracle.  No GPU work."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as entry  # noqa: E402
+
+import _ofri  # noqa: E402
+from oracle import gauss  # noqa: E402
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(_ofri.LIB_PATH):
+        entry.build()
+    lib = _ofri.lib()
+    names = entry.declared_symbols()
+    assert len(names) >= 30
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    unbound = [n for n in names if n not in _ofri._PROTOS]
+    assert not unbound, "ctypes prototypes missing for %s" % unbound
+    assert lib.ofri_version() >= 100
+
+
+def test_error_convention_without_gpu_or_bad_args():
+    lib = _ofri.lib()
+    n = C.c_int(-1)
+    lib.ofri_device_count(C.byref(n))
+    assert n.value >= 0
+    h = C.c_void_p()
+    rc = lib.ofri_ctx_create(10 ** 6, None, C.byref(h))
+    assert rc < 0 and not h.value
+    assert lib.ofri_last_error()
+    assert lib.ofri_ctx_sync(None) == -1            # OFRI_EINVAL, no crash
+    assert b"null" in lib.ofri_last_error()
+    if _ofri.device_count() == 0:
+        with pytest.raises(_ofri.OfriError):
+            _ofri.Context(0)
+
+
+@pytest.mark.parametrize("sigma,K", [(3.4, 3), (2.0, 3), (0.48, 5), (1.0, 7), (1.8, 73), (0.7, 9), (5.3, 33), (2.5, 127)])
+def test_gauss_taps_match_oracle(sigma, K):
+    import gaussian_filter as gf
+    np.testing.assert_array_equal(gf.prepareGaussianKernel(sigma, K), gauss.prepare_kernel(sigma, K))
+
+
+def test_adapter_protocol_surface():
+    from HornSchunck import HSOpticalFlowAlgoAdapter
+    ad = HSOpticalFlowAlgoAdapter([1.0, 2.0], 10)
+    assert ad.getAlgoName() == 'Horn-Schunck'
+    assert ad.hasGenericPyramidalDefaults() is True
+    assert ad.getGenericPyramidalDefaults() == {'warping': True, 'biLinear': True, 'scaling': True}
+    assert HSOpticalFlowAlgoAdapter([1.0], 5, provideGenericPyramidalDefaults=False).hasGenericPyramidalDefaults() is False
+    from GenericPyramidalOpticalFlowWrapper import GenericPyramidalOpticalFlowWrapper
+    w = GenericPyramidalOpticalFlowWrapper(ad, filter_sigma=3.4, pyr_levels=2)
+    assert w.pyr_levels == 2 and w.k_levels == 1 and w.warping is True and w.pyramidal_scaling is False
+
+
+def test_synthetic_pair_is_deterministic_and_piv_like():
+    from piv_synth import synth_piv, poiseuille_u
+    a, b = synth_piv(128, 160, seed=5)
+    a2, _ = synth_piv(128, 160, seed=5)
+    np.testing.assert_array_equal(a, a2)
+    assert a.dtype == np.uint8 and a.shape == (128, 160) and a.max() > 100 and 0.2 < (a > 0).mean() < 0.7
+    u = poiseuille_u(128)
+    assert abs(u[0]) < 1e-12 and abs(u.min() + 4.0) < 1e-3
