@@ -69,8 +69,9 @@ int ofri_event_elapsed_ms(ofri_event *start, ofri_event *stop, float *ms);      
 int ofri_event_destroy(ofri_event *ev);
 
 /* ---- Gaussian pre-filter -------------------------------------------------------------------- */
-/* convolveSeparableFilter (src/gaussian_filter.py:54-85): rows pass then columns pass, symmetric
- * reflect border (edge sample repeated), float32 sequential accumulation.  dst may equal src (the
+/* convolveSeparableFilter (src/gaussian_filter.py:54-85): rows pass then columns pass, float32
+ * sequential accumulation; border as the reference pads it (:63-66): mirrored with the edge sample
+ * repeated on the low side, the last K/2 samples repeated in their original order on the high side.  dst may equal src (the
  * reference filters in place).  taps_host: ntaps float32 values (ntaps odd, <= 127,
  * ntaps/2 <= min(rows, cols)). */
 int ofri_gauss_sep(ofri_ctx *ctx, const float *src, float *dst, int rows, int cols,

@@ -4,6 +4,15 @@
 
 #define GAUSS_MAX_TAPS 127
 
+// Border rule of the reference's pad (gaussian_filter.py:63-66,75-78).  Left of the line the samples are
+// mirrored with the edge sample repeated (-1 -> 0, -2 -> 1); right of it the reference copies the last
+// K/2 samples in their ORIGINAL order (n -> n-h, n+1 -> n-h+1, ...), which equals the mirror only for K = 3.
+__device__ __forceinline__ int gauss_idx(int i, int n, int h) {
+    if (i < 0) return -i - 1;
+    if (i >= n) return i - h;
+    return i;
+}
+
 // prepareGaussianKernel (gaussian_filter.py:47-52): offsets arange(-K/2, K/2) cast to int (truncation
 // toward zero of -K/2 + i), float64 pdf stored to float32, divided by the float32 sum of the taps.
 extern "C" int ofri_gauss_taps(double sigma, int ksize, float *taps_host) {
@@ -49,9 +58,9 @@ __global__ void k_gauss_pass(const float *__restrict__ in, float *__restrict__ o
     float acc = 0.f;
     if (AXIS == 1) {
         const float *row = in + (size_t)y * W;
-        for (int j = 0; j < K; ++j) acc = __fadd_rn(acc, __fmul_rn(row[reflsym(x + h - j, W)], taps.k[j]));
+        for (int j = 0; j < K; ++j) acc = __fadd_rn(acc, __fmul_rn(row[gauss_idx(x + h - j, W, h)], taps.k[j]));
     } else {
-        for (int j = 0; j < K; ++j) acc = __fadd_rn(acc, __fmul_rn(in[(size_t)reflsym(y + h - j, H) * W + x], taps.k[j]));
+        for (int j = 0; j < K; ++j) acc = __fadd_rn(acc, __fmul_rn(in[(size_t)gauss_idx(y + h - j, H, h) * W + x], taps.k[j]));
     }
     out[(size_t)y * W + x] = acc;
 }
@@ -68,17 +77,18 @@ k_gauss_fused(const float *__restrict__ in, float *__restrict__ out, int H, int 
     __shared__ float rowf[GT_Y + 2 * h][GT_X + 1];
     const int bx = blockIdx.x * GT_X, by = blockIdx.y * GT_Y;
     const int tid = threadIdx.y * 64 + threadIdx.x;
-    // stage 1: row-filtered values for tile rows by-h .. by+GT_Y+h-1 (symmetric reflect in y applies to
-    // the row-filtered image, which equals row-filtering the reflected source row)
+    // stage 1: row-filtered values for tile rows by-h .. by+GT_Y+h-1 (the border rule in y applies to
+    // the row-filtered image, which equals row-filtering the border-mapped source row)
     for (int i = tid; i < (GT_Y + 2 * h) * GT_X; i += 256) {
         int ly = i / GT_X, lx = i % GT_X;
         int x = bx + lx;
-        int y = reflsym(by + ly - h, H);
+        int y = clampi(gauss_idx(by + ly - h, H, h), 0, H - 1);
         float acc = 0.f;
-        if (x < W) {
+        // rows further than h below the image are never consumed (and would not reflect validly)
+        if (x < W && by + ly - h <= H - 1 + h) {
             const float *row = in + (size_t)y * W;
 #pragma unroll
-            for (int j = 0; j < K; ++j) acc = __fadd_rn(acc, __fmul_rn(row[reflsym(x + h - j, W)], taps.k[j]));
+            for (int j = 0; j < K; ++j) acc = __fadd_rn(acc, __fmul_rn(row[gauss_idx(x + h - j, W, h)], taps.k[j]));
         }
         rowf[ly][lx] = acc;
     }

@@ -15,7 +15,8 @@ def prepare_kernel(sigma, ksize):
 def _pass_rows(img, k):
     """One 1-D pass along axis 1 (gaussian_filter.py:62-71 with convolveDirect :24-45).
 
-    Border: symmetric reflect, edge sample repeated (:63-66).  Output p accumulates
+    Border (:63-66): low side mirrored with the edge sample repeated; high side = the last K//2
+    samples copied in their original order (a mirror only when K == 3).  Output p accumulates
     pad[p + K-1 - j] * k[j] for j = 0..K-1 in float32, starting from 0 (:37-40)."""
     K = k.shape[0]
     h = K // 2
