@@ -1,6 +1,7 @@
 // Horn-Schunck: derivative cube, Jacobi sweeps, error norm.
 // Reference behaviour: src/HornSchunck.py:52-127 (HS_helper2, HS_helper, HS, computeDerivatives).
 #include "ofri_internal.h"
+#include "ofri_hs_math.h"
 
 int ofri_norm_diff_dev(ofri_ctx *ctx, const float *a, const float *b, size_t n, int slot);
 int ofri_read_slots(ofri_ctx *ctx, int first, int count, double *out_host);
@@ -48,7 +49,8 @@ extern "C" int ofri_hs_derivs(ofri_ctx *ctx, const float *first, const float *se
 //   ubar = K*U, vbar = K*V  (K = [[1/12,1/6,1/12],[1/6,0,1/6],[1/12,1/6,1/12]] in float32, 'mirror')
 //   der  = (fx*ubar + fy*vbar + ft) / (alpha^2 + fx^2 + fy^2);  U = ubar - fx*der;  V = vbar - fy*der
 // EXACT = true follows scipy's float64 tap-by-tap accumulation and NumPy's unfused float32 element
-// ops, so the result is bit-identical to the reference; EXACT = false is plain float32 with FMAs.
+// ops, so the result is bit-identical to the reference; EXACT = false is float32 with a pinned
+// operation order (ofri_hs_math.h) and a reciprocal of the denominator instead of a division.
 #define W6  0.16666667163372040   // float32(1/6)  as a double
 #define W12 0.08333333581686020   // float32(1/12) as a double
 
@@ -66,7 +68,7 @@ __device__ __forceinline__ float avg9(float a00, float a01, float a02, float a10
         t = __dadd_rn(t, __dmul_rn((double)a22, W12));
         return (float)t;
     } else {
-        return ((a01 + a21) + (a10 + a12)) * (float)W6 + ((a00 + a02) + (a20 + a22)) * (float)W12;
+        return hs_avg(__fadd_rn(__fadd_rn(a01, a21), __fadd_rn(a10, a12)), __fadd_rn(__fadd_rn(a00, a20), __fadd_rn(a02, a22)));
     }
 }
 
@@ -80,10 +82,7 @@ __device__ __forceinline__ void hs_point(float ua, float va, float fx, float fy,
         un = __fsub_rn(ua, __fmul_rn(fx, der));
         vn = __fsub_rn(va, __fmul_rn(fy, der));
     } else {
-        float den = a2 + fx * fx + fy * fy;
-        float der = (fx * ua + fy * va + ft) / den;
-        un = ua - fx * der;
-        vn = va - fy * der;
+        hs_update(ua, va, fx, fy, ft, hs_rden(fx, fy, a2), un, vn);
     }
 }
 

@@ -1,8 +1,175 @@
-// Temporally blocked Horn-Schunck sweeps (several Jacobi sweeps per launch).
+// Temporally blocked Horn-Schunck: T Jacobi sweeps per launch on a register-resident tile.
+//
+// A 256-thread workgroup owns a region of FT_RX x FT_RY = 128 x 64 pixels (output tile 112 x 48 plus a
+// halo of 8).  Lane l of band b (one band = 32 lanes = 8 rows) keeps a column strip of 4 x 8 pixels of
+// U, V, fx, fy, ft and 1/den in registers.  Per sweep the left/right neighbours come from the adjacent
+// lanes (DPP wave shifts), the rows above/below the strip from a small double-buffered LDS array of band
+// edge rows; one barrier per sweep.  Pixels within s of the region border are stale after s sweeps, which
+// is why only the inner 112 x 48 pixels are stored after T <= 8 sweeps.  Region pixels outside the image
+// are loaded from their mirror image ('mirror' border: a field extended by reflection stays the
+// reflection of itself under the symmetric averaging stencil), so borders need no special case.
 #include "ofri_internal.h"
+#include "ofri_hs_math.h"
 
+#define FT_HALO 8
+#define FT_RX 128
+#define FT_RY 64
+#define FT_OX (FT_RX - 2 * FT_HALO)
+#define FT_OY (FT_RY - 2 * FT_HALO)
+#define FT_S 8                       // rows per thread
+#define FT_BANDS (FT_RY / FT_S)      // 8 bands of 32 lanes
+
+__device__ __forceinline__ float lane_left(float v) {    // value held by lane-1 (wave_shr:1)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float lane_right(float v) {   // value held by lane+1 (wave_shl:1)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xF, 0xF, false));
+}
+// reflect-101 for any overshoot
+__device__ __forceinline__ int refl101_any(int i, int n) {
+    if (n == 1) return 0;
+    int p = 2 * n - 2;
+    i %= p;
+    if (i < 0) i += p;
+    return i < n ? i : p - i;
+}
+
+__global__ void __launch_bounds__(256, 2)
+k_hs_fused(const float *__restrict__ U, const float *__restrict__ V, const float *__restrict__ fx,
+           const float *__restrict__ fy, const float *__restrict__ ft, float *__restrict__ Un,
+           float *__restrict__ Vn, float a2, int H, int W, int T, int tiles_x, int ntiles) {
+    // [buffer][slot][top/bottom][U/V][lane]; slot b+1 belongs to band b, slots 0 and FT_BANDS+1 are never written
+    __shared__ float4 edge[2][FT_BANDS + 2][2][2][32];
+    __shared__ float4 ftile[FT_RY][32];          // ft of the region: read-only after the load, kept out of registers
+    const int tid = threadIdx.x, l32 = tid & 31, band = tid >> 5;
+
+    // XCD-aware tile order: workgroups b, b+8, b+16, ... share an XCD (and its L2), so give each of the
+    // 8 residue classes a contiguous run of tiles; neighbouring tiles share their halo reads
+    int b = blockIdx.x, q = ntiles >> 3, r8 = ntiles & 7, xcd = b & 7;
+    int t = xcd * q + (xcd < r8 ? xcd : r8) + (b >> 3);
+    const int ty = t / tiles_x, tx = t - ty * tiles_x;
+    const int gx0 = tx * FT_OX - FT_HALO + l32 * 4;
+    const int gyb = ty * FT_OY - FT_HALO + band * FT_S;
+    const bool xin = gx0 >= 0 && gx0 + 3 < W;
+
+    float cu[FT_S][4], cv[FT_S][4], gx[FT_S][4], gy[FT_S][4], rd[FT_S][4];
+#pragma unroll
+    for (int r = 0; r < FT_S; ++r) {
+        int y = gyb + r;
+        if (xin && y >= 0 && y < H) {
+            size_t o = (size_t)y * W + gx0;
+            float4 a = *reinterpret_cast<const float4 *>(U + o), bb = *reinterpret_cast<const float4 *>(V + o);
+            float4 c = *reinterpret_cast<const float4 *>(fx + o), d = *reinterpret_cast<const float4 *>(fy + o);
+            float4 e = *reinterpret_cast<const float4 *>(ft + o);
+            cu[r][0] = a.x; cu[r][1] = a.y; cu[r][2] = a.z; cu[r][3] = a.w;
+            cv[r][0] = bb.x; cv[r][1] = bb.y; cv[r][2] = bb.z; cv[r][3] = bb.w;
+            gx[r][0] = c.x; gx[r][1] = c.y; gx[r][2] = c.z; gx[r][3] = c.w;
+            gy[r][0] = d.x; gy[r][1] = d.y; gy[r][2] = d.z; gy[r][3] = d.w;
+            ftile[band * FT_S + r][l32] = e;
+        } else {
+            size_t ro = (size_t)refl101_any(y, H) * W;
+            float e[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                size_t o = ro + refl101_any(gx0 + k, W);
+                cu[r][k] = U[o]; cv[r][k] = V[o]; gx[r][k] = fx[o]; gy[r][k] = fy[o]; e[k] = ft[o];
+            }
+            ftile[band * FT_S + r][l32] = make_float4(e[0], e[1], e[2], e[3]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < FT_S; ++r)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) rd[r][k] = hs_rden(gx[r][k], gy[r][k], a2);
+
+    if (tid < 64) {   // the two slots nobody owns: rows outside the region, never valid, keep them finite
+        float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        int s = (tid & 32) ? FT_BANDS + 1 : 0;
+        edge[0][s][0][0][l32] = z; edge[0][s][0][1][l32] = z; edge[0][s][1][0][l32] = z; edge[0][s][1][1][l32] = z;
+        edge[1][s][0][0][l32] = z; edge[1][s][0][1][l32] = z; edge[1][s][1][0][l32] = z; edge[1][s][1][1][l32] = z;
+    }
+    edge[0][band + 1][0][0][l32] = make_float4(cu[0][0], cu[0][1], cu[0][2], cu[0][3]);
+    edge[0][band + 1][0][1][l32] = make_float4(cv[0][0], cv[0][1], cv[0][2], cv[0][3]);
+    edge[0][band + 1][1][0][l32] = make_float4(cu[FT_S - 1][0], cu[FT_S - 1][1], cu[FT_S - 1][2], cu[FT_S - 1][3]);
+    edge[0][band + 1][1][1][l32] = make_float4(cv[FT_S - 1][0], cv[FT_S - 1][1], cv[FT_S - 1][2], cv[FT_S - 1][3]);
+    __syncthreads();
+
+    for (int s = 0; s < T; ++s) {
+        const int buf = s & 1;
+        float4 upU = edge[buf][band][1][0][l32], upV = edge[buf][band][1][1][l32];          // bottom row of the band above
+        float4 dnU = edge[buf][band + 2][0][0][l32], dnV = edge[buf][band + 2][0][1][l32];  // top row of the band below
+        float pu[4] = {upU.x, upU.y, upU.z, upU.w}, pv[4] = {upV.x, upV.y, upV.z, upV.w};
+#pragma unroll
+        for (int r = 0; r < FT_S; ++r) {
+            float nu[4], nv[4];
+            if (r < FT_S - 1) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { nu[k] = cu[r + 1][k]; nv[k] = cv[r + 1][k]; }
+            } else {
+                nu[0] = dnU.x; nu[1] = dnU.y; nu[2] = dnU.z; nu[3] = dnU.w;
+                nv[0] = dnV.x; nv[1] = dnV.y; nv[2] = dnV.z; nv[3] = dnV.w;
+            }
+            // vertical pair sums and centre values for columns x0-1 .. x0+4
+            float su[6], sv[6], eu[6], ev[6];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                su[k + 1] = __fadd_rn(pu[k], nu[k]); sv[k + 1] = __fadd_rn(pv[k], nv[k]);
+                eu[k + 1] = cu[r][k]; ev[k + 1] = cv[r][k];
+            }
+            su[0] = lane_left(su[4]); su[5] = lane_right(su[1]);
+            sv[0] = lane_left(sv[4]); sv[5] = lane_right(sv[1]);
+            eu[0] = lane_left(eu[4]); eu[5] = lane_right(eu[1]);
+            ev[0] = lane_left(ev[4]); ev[5] = lane_right(ev[1]);
+            float tu[4], tv[4];
+            const float4 g4 = ftile[band * FT_S + r][l32];
+            const float gt[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float ua = hs_avg(__fadd_rn(su[k + 1], __fadd_rn(eu[k], eu[k + 2])), __fadd_rn(su[k], su[k + 2]));
+                float va = hs_avg(__fadd_rn(sv[k + 1], __fadd_rn(ev[k], ev[k + 2])), __fadd_rn(sv[k], sv[k + 2]));
+                hs_update(ua, va, gx[r][k], gy[r][k], gt[k], rd[r][k], tu[k], tv[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { pu[k] = cu[r][k]; pv[k] = cv[r][k]; cu[r][k] = tu[k]; cv[r][k] = tv[k]; }
+        }
+        edge[buf ^ 1][band + 1][0][0][l32] = make_float4(cu[0][0], cu[0][1], cu[0][2], cu[0][3]);
+        edge[buf ^ 1][band + 1][0][1][l32] = make_float4(cv[0][0], cv[0][1], cv[0][2], cv[0][3]);
+        edge[buf ^ 1][band + 1][1][0][l32] = make_float4(cu[FT_S - 1][0], cu[FT_S - 1][1], cu[FT_S - 1][2], cu[FT_S - 1][3]);
+        edge[buf ^ 1][band + 1][1][1][l32] = make_float4(cv[FT_S - 1][0], cv[FT_S - 1][1], cv[FT_S - 1][2], cv[FT_S - 1][3]);
+        __syncthreads();
+    }
+
+    // store the inner tile: bands 1..FT_BANDS-2, strips 2..29, clipped to the image
+    if (band >= FT_HALO / FT_S && band < FT_BANDS - FT_HALO / FT_S && l32 >= FT_HALO / 4 && l32 < 32 - FT_HALO / 4 && xin) {
+#pragma unroll
+        for (int r = 0; r < FT_S; ++r) {
+            int y = gyb + r;
+            if (y < H) {
+                size_t o = (size_t)y * W + gx0;
+                *reinterpret_cast<float4 *>(Un + o) = make_float4(cu[r][0], cu[r][1], cu[r][2], cu[r][3]);
+                *reinterpret_cast<float4 *>(Vn + o) = make_float4(cv[r][0], cv[r][1], cv[r][2], cv[r][3]);
+            }
+        }
+    }
+}
+
+// Runs as many fused passes as fit and leaves the remainder (remaining) to the caller; swaps the
+// ping-pong pointers once per pass.
 int ofri_hs_fused_passes(ofri_ctx *ctx, float *&cu, float *&cv, float *&nu, float *&nv, const float *fx,
                          const float *fy, const float *ft, float a2, int &remaining, int &launches, int H, int W) {
-    (void)ctx; (void)cu; (void)cv; (void)nu; (void)nv; (void)fx; (void)fy; (void)ft; (void)a2; (void)remaining; (void)launches; (void)H; (void)W;
+    const bool aligned = ((((size_t)cu | (size_t)cv | (size_t)fx | (size_t)fy | (size_t)ft | (size_t)nu | (size_t)nv) & 15) == 0);
+    if (!aligned || (W & 3) || W < 16 || H < 16) return OFRI_OK;
+    int Tmax = ctx->hs_fuse > 1 ? ctx->hs_fuse : FT_HALO;
+    if (Tmax > FT_HALO) Tmax = FT_HALO;
+    const int tiles_x = ceil_div(W, FT_OX), tiles_y = ceil_div(H, FT_OY), ntiles = tiles_x * tiles_y;
+    while (remaining > 0) {
+        int T = remaining < Tmax ? remaining : Tmax;
+        k_hs_fused<<<ntiles, 256, 0, ctx->stream>>>(cu, cv, fx, fy, ft, nu, nv, a2, H, W, T, tiles_x, ntiles);
+        OFRI_LAUNCH_CHECK();
+        float *t = cu; cu = nu; nu = t;
+        t = cv; cv = nv; nv = t;
+        remaining -= T;
+        ++launches;
+    }
     return OFRI_OK;
 }
