@@ -104,6 +104,17 @@ int ofri_hs_compute(ofri_ctx *ctx, const float *frame0, const float *frame1,
                     const float *U_in, const float *V_in, float *U_out, float *V_out,
                     float alpha, int niter, int rows, int cols, double *err_host);
 
+/* ---- Liu-Shen physics-based refinement --------------------------------------------------------- */
+/* physicsBasedOpticalFlowLiuShen(im1, im2, h, U, V) (src/PhysicsBasedOpticalFlowLiuShen.py:82-158)
+ * with its own argument convention: u is the ROW-direction component, v the column-direction one
+ * (LiuShenOpticalFlowAlgoAdapter.compute swaps U/V in and out, :37-39).  Images are divided by their
+ * maxima, the coefficient fields and the inverse matrix are built, then up to maxit fixed-point
+ * sweeps run until total_error <= tol (reference: maxit 60, tol 1e-8).  The stopping rule is
+ * evaluated on the GPU; nothing blocks unless err_host / iters_host is non-NULL. */
+int ofri_ls_compute(ofri_ctx *ctx, const float *im1, const float *im2, const float *u_in,
+                    const float *v_in, float *u_out, float *v_out, float h, int maxit, double tol,
+                    int rows, int cols, double *err_host, int *iters_host);
+
 /* ---- pyramid glue --------------------------------------------------------------------------- */
 /* imresize (src/GenericPyramidalOpticalFlow.py:67-68): Pillow's scale-aware bicubic (a = -0.5) on
  * float32: horizontal then vertical pass, float64 accumulation, float32 intermediate. */

@@ -265,3 +265,54 @@ def test_full_size_properties_4096(ctx):
         outs.append((flip(d[0].numpy()), flip(d[1].numpy())))
     for k in (1, 2):
         np.testing.assert_array_equal(outs[0][0], outs[k][0]); np.testing.assert_array_equal(outs[0][1], outs[k][1])
+
+
+# ------------------------------------------------------------------------------ Liu-Shen
+def test_liushen_raw_and_adapter_vs_reference(ctx):
+    import PhysicsBasedOpticalFlowLiuShen as L
+    from oracle import gauss
+    l = load_gold("liushen")
+    pg = load_gold("pair_parabolic01")
+    I0o = gauss.filter_px(pg["im0"].astype(np.float32), 0.48, 5)[:256, :256].copy()
+    I1o = gauss.filter_px(pg["im1"].astype(np.float32), 0.48, 5)[:256, :256].copy()
+    z = np.zeros((256, 256), np.float32)
+    u, v, err = L.physicsBasedOpticalFlowLiuShen(I0o, I1o, 5, z, z.copy())
+    r = flow_rel(u, v, l["raw_h5_zero_u"], l["raw_h5_zero_v"])
+    print("liushen raw rel L2", r, "max abs", np.abs(u - l["raw_h5_zero_u"]).max())
+    assert r < 1e-5
+    assert err == pytest.approx(float(l["raw_h5_zero_err"]), rel=1e-3)
+    a, b, e, it = L.liushen_device(ctx.upload(I0o), ctx.upload(I1o), 5, ctx.upload(z), ctx.upload(z), True)
+    assert it == str(l["raw_h5_zero_log"]).count("Iteration:")
+    # adapter: swaps the components in and out, ragged 57 x 71 crop, random initial flow
+    U, V, err = L.LiuShenOpticalFlowAlgoAdapter(10).compute(l["crop_im0"].copy(), l["crop_im1"].copy(), l["crop_Uin"].copy(), l["crop_Vin"].copy())
+    assert flow_rel(U, V, l["crop_U"], l["crop_V"]) < 1e-5
+    assert err == pytest.approx(float(l["crop_err"]), rel=1e-3)
+
+
+def test_liushen_stopping_rule_and_tiny_shapes(ctx):
+    import PhysicsBasedOpticalFlowLiuShen as L
+    from oracle import liushen
+    rng = np.random.default_rng(3)
+    # a flat image pair converges at once: coefficient fields vanish and u, v collapse to 0
+    for shape in ((1, 1), (1, 6), (7, 1), (5, 9), (66, 130)):
+        a = (rng.uniform(1, 255, shape)).astype(np.float32); b = (rng.uniform(1, 255, shape)).astype(np.float32)
+        U0 = (0.1 * rng.standard_normal(shape)).astype(np.float32); V0 = (0.1 * rng.standard_normal(shape)).astype(np.float32)
+        ur, vr, er, itr = liushen.liushen(a, b, 50.0, U0.copy(), V0.copy(), return_iters=True)
+        ud, vd, ed, itd = L.liushen_device(ctx.upload(a), ctx.upload(b), 50.0, ctx.upload(U0), ctx.upload(V0), True)
+        assert itd == itr, shape
+        assert flow_rel(ud.numpy(), vd.numpy(), ur, vr) < 1e-5, shape
+    flat = np.full((32, 48), 7.0, np.float32)
+    ud, vd, ed, itd = L.liushen_device(ctx.upload(flat), ctx.upload(flat), 5.0, ctx.zeros(flat.shape), ctx.zeros(flat.shape), True)
+    ur, vr, er, itr = liushen.liushen(flat, flat, 5.0, np.zeros_like(flat), np.zeros_like(flat), return_iters=True)
+    assert itd == itr and itd < 60
+    np.testing.assert_array_equal(ud.numpy(), ur)
+
+
+def test_driver_hs_plus_liushen_and_ls_main(ctx, pair):
+    from HornSchunck import HSOpticalFlowAlgoAdapter as A
+    from PhysicsBasedOpticalFlowLiuShen import LiuShenOpticalFlowAlgoAdapter as LS
+    from GenericPyramidalOpticalFlow import genericPyramidalOpticalFlow as flow
+    I0, I1 = pair
+    r1 = _driver_case("hs_L2_ls", *flow(I0, I1, 3.4, A([21, 45], 100), 2, 1, 0.48, LS(5)))
+    r2 = _driver_case("ls_main_L2", *flow(I0[:256, :256].copy(), I1[:256, :256].copy(), 3.4, LS(0.1), 2, 1, None, None, True, True, True, True))
+    print("driver rel L2 vs reference: hs_L2_ls", r1, "ls_main_L2", r2)
