@@ -115,6 +115,32 @@ int ofri_ls_compute(ofri_ctx *ctx, const float *im1, const float *im2, const flo
                     const float *v_in, float *u_out, float *v_out, float h, int maxit, double tol,
                     int rows, int cols, double *err_host, int *iters_host);
 
+/* ---- Farneback polynomial expansion --------------------------------------------------------------- */
+/* 5-plane arrays (R0, R1, M) hold their planes stacked vertically: plane k is rows k*rows..(k+1)*rows-1
+ * of a (5*rows, cols) float32 array, as in the reference (src/Farneback_PyCL.py:542-545).
+ * polynomialExpansion (src/optical_flow_farneback.cl:72-133; host src/Farneback_PyCL.py:311-356):
+ * g/xg/xxg_host are the non-negative halves (polyN+1 floats), ig_host = {ig11, ig03, ig33, ig55}. */
+int ofri_fb_polyexp(ofri_ctx *ctx, const float *src, float *dst5, int rows, int cols, int polyN,
+                    const float *g_host, const float *xg_host, const float *xxg_host, const float *ig_host);
+/* gaussianBlur / gaussianBlur5 (.cl:160-253; host :211-272): separable, reflect-101 borders,
+ * half_taps_host = centre tap first, ksize_half+1 floats (ksize_half <= 100). */
+int ofri_fb_blur(ofri_ctx *ctx, const float *src, float *dst, int rows, int cols,
+                 const float *half_taps_host, int ksize_half);
+int ofri_fb_blur5(ofri_ctx *ctx, const float *src5, float *dst5, int rows, int cols,
+                  const float *half_taps_host, int ksize_half);
+/* boxFilter5 (.cl:350-406; host :274-309): clamped borders, mean over (2*ksize_half+1)^2 */
+int ofri_fb_box5(ofri_ctx *ctx, const float *src5, float *dst5, int rows, int cols, int ksize_half);
+/* updateMatrices (.cl:256-348; host :391-423) */
+int ofri_fb_update_matrices(ofri_ctx *ctx, const float *flowx, const float *flowy, const float *R0,
+                            const float *R1, float *M, int rows, int cols);
+/* updateFlow (.cl:408-429; host :358-389) */
+int ofri_fb_update_flow(ofri_ctx *ctx, const float *M, float *flowx, float *flowy, int rows, int cols);
+/* gaussianBlur5 (box != 0: boxFilter5) followed by updateFlow in one pass, the pairing used by
+ * updateFlowGaussianBlur / updateFlowBoxFilter (src/Farneback_PyCL.py:425-457): the filtered
+ * matrices are consumed in registers and never written. */
+int ofri_fb_window5_update_flow(ofri_ctx *ctx, const float *M5, float *flowx, float *flowy, int rows,
+                                int cols, const float *half_taps_host, int ksize_half, int box);
+
 /* ---- pyramid glue --------------------------------------------------------------------------- */
 /* imresize (src/GenericPyramidalOpticalFlow.py:67-68): Pillow's scale-aware bicubic (a = -0.5) on
  * float32: horizontal then vertical pass, float64 accumulation, float32 intermediate. */

@@ -53,6 +53,13 @@ _PROTOS = {
     "ofri_prof_read": ([_vp, _i, C.POINTER(_f), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)], _i),
     "ofri_hs_compute": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, C.POINTER(_d)], _i),
     "ofri_ls_compute": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _d, _i, _i, C.POINTER(_d), C.POINTER(_i)], _i),
+    "ofri_fb_polyexp": ([_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp], _i),
+    "ofri_fb_blur": ([_vp, _vp, _vp, _i, _i, _vp, _i], _i),
+    "ofri_fb_blur5": ([_vp, _vp, _vp, _i, _i, _vp, _i], _i),
+    "ofri_fb_box5": ([_vp, _vp, _vp, _i, _i, _i], _i),
+    "ofri_fb_update_matrices": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i], _i),
+    "ofri_fb_update_flow": ([_vp, _vp, _vp, _vp, _i, _i], _i),
+    "ofri_fb_window5_update_flow": ([_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i], _i),
     "ofri_resize_bicubic": ([_vp, _vp, _i, _i, _vp, _i, _i], _i),
     "ofri_resize_bilinear": ([_vp, _vp, _i, _i, _vp, _i, _i], _i),
     "ofri_spline_upsample": ([_vp, _vp, _i, _i, _vp, _i, _i, _f], _i),

@@ -1,0 +1,279 @@
+// Farneback polynomial-expansion optical flow kernels.
+// Reference behaviour: src/optical_flow_farneback.cl:72-429 (OpenCV-derived OpenCL kernels) and their
+// host wrappers src/Farneback_PyCL.py:211-457.  Arithmetic follows the kernel text operation by
+// operation in float32 with separately rounded products and sums (no FMA contraction in this file).
+#include "ofri_internal.h"
+#pragma clang fp contract(off)
+
+#define FB_MAX_KSH 100                 // MAX_KSIZE_HALF of the reference
+struct FbTaps { float k[FB_MAX_KSH + 1]; };
+struct FbPoly { float g[8], xg[8], xxg[8], ig[4]; };
+
+// border index helpers of the reference (.cl:135-158): reflect-101 with a modulo guard
+__device__ __forceinline__ int fb_low(int y, int last) { return abs(y) % (last + 1); }
+__device__ __forceinline__ int fb_high(int y, int last) { return abs(last - abs(last - y)) % (last + 1); }
+__device__ __forceinline__ int fb_idx(int t, int last) { return fb_low(fb_high(t, last), last); }
+
+// ---- polynomial expansion (.cl:72-133) -----------------------------------------------------------
+#define PE_TX 64
+#define PE_TY 8
+template <int N>
+__global__ void __launch_bounds__(256)
+k_fb_polyexp(const float *__restrict__ src, float *__restrict__ dst, int H, int W, FbPoly c) {
+    __shared__ float r0[PE_TY][PE_TX + 2 * N], r1[PE_TY][PE_TX + 2 * N], r2[PE_TY][PE_TX + 2 * N];
+    const int bx = blockIdx.x * PE_TX, by = blockIdx.y * PE_TY, tid = threadIdx.y * 64 + threadIdx.x;
+    // vertical pass; rows clamped (:98-99), columns clamped (:89)
+    for (int i = tid; i < PE_TY * (PE_TX + 2 * N); i += 256) {
+        int ly = i / (PE_TX + 2 * N), lx = i - ly * (PE_TX + 2 * N);
+        int y = by + ly, x = clampi(bx + lx - N, 0, W - 1);
+        float a = 0.f, b = 0.f, d = 0.f;
+        if (y < H) {
+            a = src[(size_t)y * W + x] * c.g[0];
+#pragma unroll
+            for (int k = 1; k <= N; ++k) {
+                float t0 = src[(size_t)max(y - k, 0) * W + x];
+                float t1 = src[(size_t)min(y + k, H - 1) * W + x];
+                a += c.g[k] * (t0 + t1);
+                b += c.xg[k] * (t1 - t0);
+                d += c.xxg[k] * (t0 + t1);
+            }
+        }
+        r0[ly][lx] = a; r1[ly][lx] = b; r2[ly][lx] = d;
+    }
+    __syncthreads();
+    for (int i = tid; i < PE_TY * PE_TX; i += 256) {
+        int ly = i / PE_TX, lx = i - ly * PE_TX;
+        int y = by + ly, x = bx + lx;
+        if (y >= H || x >= W) continue;
+        const float *p0 = &r0[ly][lx + N], *p1 = &r1[ly][lx + N], *p2 = &r2[ly][lx + N];
+        float b1 = c.g[0] * p0[0], b3 = c.g[0] * p1[0], b5 = c.g[0] * p2[0], b2 = 0.f, b4 = 0.f, b6 = 0.f;
+#pragma unroll
+        for (int k = 1; k <= N; ++k) {
+            b1 += (p0[k] + p0[-k]) * c.g[k];
+            b4 += (p0[k] + p0[-k]) * c.xxg[k];
+            b2 += (p0[k] - p0[-k]) * c.xg[k];
+            b3 += (p1[k] + p1[-k]) * c.g[k];
+            b6 += (p1[k] - p1[-k]) * c.xg[k];
+            b5 += (p2[k] + p2[-k]) * c.g[k];
+        }
+        size_t o = (size_t)y * W + x, P = (size_t)H * W;
+        dst[o] = b3 * c.ig[0];
+        dst[P + o] = b2 * c.ig[0];
+        dst[2 * P + o] = b1 * c.ig[1] + b5 * c.ig[2];
+        dst[3 * P + o] = b1 * c.ig[1] + b4 * c.ig[2];
+        dst[4 * P + o] = b6 * c.ig[3];
+    }
+}
+
+extern "C" int ofri_fb_polyexp(ofri_ctx *ctx, const float *src, float *dst5, int rows, int cols, int polyN,
+                               const float *g_host, const float *xg_host, const float *xxg_host, const float *ig_host) {
+    OFRI_TRY(ofri_check_ctx(ctx));
+    OFRI_REQUIRE(src && dst5 && g_host && xg_host && xxg_host && ig_host, "null pointer");
+    OFRI_REQUIRE(rows > 0 && cols > 0, "bad shape");
+    OFRI_REQUIRE(polyN == 5 || polyN == 7, "polyN must be 5 or 7");       // Farneback_PyCL.py:463
+    FbPoly c;
+    memset(&c, 0, sizeof(c));
+    memcpy(c.g, g_host, (polyN + 1) * sizeof(float));
+    memcpy(c.xg, xg_host, (polyN + 1) * sizeof(float));
+    memcpy(c.xxg, xxg_host, (polyN + 1) * sizeof(float));
+    memcpy(c.ig, ig_host, 4 * sizeof(float));
+    dim3 b(64, 4), g(ceil_div(cols, PE_TX), ceil_div(rows, PE_TY));
+    if (polyN == 5) k_fb_polyexp<5><<<g, b, 0, ctx->stream>>>(src, dst5, rows, cols, c);
+    else k_fb_polyexp<7><<<g, b, 0, ctx->stream>>>(src, dst5, rows, cols, c);
+    OFRI_LAUNCH_CHECK();
+    return OFRI_OK;
+}
+
+// ---- separable window filter on NP stacked planes (.cl:160-253, 350-406) -------------------------
+// One workgroup: 64 x 16 outputs.  Per plane the (16+2k) x (64+2k) source tile goes to LDS once, the
+// vertical pass writes 16 x (64+2k) partial sums to LDS, the horizontal pass leaves 4 results per
+// thread in registers.  MODE 0: Gaussian taps, reflect-101 border.  MODE 1: box, clamped border.
+// FLOW: instead of storing the NP = 5 filtered planes, solve the 2x2 system per pixel (.cl:408-429).
+#define BL_TX 64
+#define BL_TY 16
+template <int NP, int MODE, bool FLOW>
+__global__ void __launch_bounds__(256)
+k_fb_window(const float *__restrict__ src, float *__restrict__ dst, float *__restrict__ flowx, float *__restrict__ flowy,
+            int H, int W, int ksh, FbTaps taps) {
+    extern __shared__ float lds[];
+    const int TW = BL_TX + 2 * ksh, TH = BL_TY + 2 * ksh;
+    float *tin = lds;                     // TH x TW
+    float *tv = lds + (size_t)TH * TW;    // BL_TY x TW
+    const int bx = blockIdx.x * BL_TX, by = blockIdx.y * BL_TY, tid = threadIdx.y * 64 + threadIdx.x;
+    const size_t P = (size_t)H * W;
+    float res[NP][4];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const float *sp = src + p * P;
+        for (int i = tid; i < TH * TW; i += 256) {
+            int ly = i / TW, lx = i - ly * TW;
+            int y = by + ly - ksh, x = bx + lx - ksh;
+            if (MODE == 0) { y = fb_idx(y, H - 1); x = fb_idx(x, W - 1); }
+            else { y = clampi(y, 0, H - 1); x = clampi(x, 0, W - 1); }
+            tin[i] = sp[(size_t)y * W + x];
+        }
+        __syncthreads();
+        for (int i = tid; i < BL_TY * TW; i += 256) {
+            int ly = i / TW, lx = i - ly * TW;
+            const float *c = tin + (size_t)(ly + ksh) * TW + lx;
+            float acc = MODE == 0 ? c[0] * taps.k[0] : c[0];
+            for (int j = 1; j <= ksh; ++j) {
+                float s = c[-j * TW] + c[j * TW];
+                acc += MODE == 0 ? s * taps.k[j] : s;
+            }
+            tv[i] = acc;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float *c = tv + (size_t)(threadIdx.y * 4 + r) * TW + threadIdx.x + ksh;
+            float acc = MODE == 0 ? c[0] * taps.k[0] : c[0];
+            for (int i = 1; i <= ksh; ++i) {
+                float s = c[-i] + c[i];
+                acc += MODE == 0 ? s * taps.k[i] : s;
+            }
+            res[p][r] = acc;
+        }
+        // the next plane's load overwrites tin only; tv is rewritten after the barrier that follows that load
+    }
+    const float box_inv = 1.f / ((1 + 2 * ksh) * (1 + 2 * ksh));
+    const int x = bx + threadIdx.x;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        int y = by + threadIdx.y * 4 + r;
+        if (x >= W || y >= H) continue;
+        size_t o = (size_t)y * W + x;
+        float v[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) v[p] = MODE == 0 ? res[p][r] : res[p][r] * box_inv;
+        if (FLOW) {
+            float g11 = v[0], g12 = v[NP > 1 ? 1 : 0], g22 = v[NP > 2 ? 2 : 0], h1 = v[NP > 3 ? 3 : 0], h2 = v[NP > 4 ? 4 : 0];
+            float detInv = 1.f / (g11 * g22 - g12 * g12 + 1e-3f);
+            flowx[o] = (g11 * h2 - g12 * h1) * detInv;
+            flowy[o] = (g22 * h1 - g12 * h2) * detInv;
+        } else {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) dst[p * P + o] = v[p];
+        }
+    }
+}
+
+template <int NP, int MODE, bool FLOW>
+static int fb_window_launch(ofri_ctx *ctx, const float *src, float *dst, float *fx, float *fy, int rows, int cols,
+                            const float *taps_host, int ksh) {
+    OFRI_TRY(ofri_check_ctx(ctx));
+    OFRI_REQUIRE(src && (FLOW ? (fx && fy) : dst != nullptr), "null pointer");
+    OFRI_REQUIRE(rows > 0 && cols > 0, "bad shape");
+    OFRI_REQUIRE(ksh >= 0 && ksh <= FB_MAX_KSH, "ksize_half out of range (0..%d)", FB_MAX_KSH);
+    OFRI_REQUIRE(MODE == 1 || taps_host, "null taps");
+    OFRI_REQUIRE(src != dst, "window filter cannot run in place");
+    FbTaps t;
+    memset(&t, 0, sizeof(t));
+    if (MODE == 0) memcpy(t.k, taps_host, (ksh + 1) * sizeof(float));
+    size_t lds = ((size_t)(BL_TY + 2 * ksh) * (BL_TX + 2 * ksh) + (size_t)BL_TY * (BL_TX + 2 * ksh)) * sizeof(float);
+    OFRI_REQUIRE(lds <= 160 * 1024, "window too large for LDS");
+    auto kern = k_fb_window<NP, MODE, FLOW>;
+    if (lds > 64 * 1024) OFRI_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    dim3 b(64, 4), g(ceil_div(cols, BL_TX), ceil_div(rows, BL_TY));
+    kern<<<g, b, lds, ctx->stream>>>(src, dst, fx, fy, rows, cols, ksh, t);
+    OFRI_LAUNCH_CHECK();
+    return OFRI_OK;
+}
+
+extern "C" int ofri_fb_blur(ofri_ctx *ctx, const float *src, float *dst, int rows, int cols,
+                            const float *half_taps_host, int ksize_half) {
+    return fb_window_launch<1, 0, false>(ctx, src, dst, nullptr, nullptr, rows, cols, half_taps_host, ksize_half);
+}
+extern "C" int ofri_fb_blur5(ofri_ctx *ctx, const float *src5, float *dst5, int rows, int cols,
+                             const float *half_taps_host, int ksize_half) {
+    return fb_window_launch<5, 0, false>(ctx, src5, dst5, nullptr, nullptr, rows, cols, half_taps_host, ksize_half);
+}
+extern "C" int ofri_fb_box5(ofri_ctx *ctx, const float *src5, float *dst5, int rows, int cols, int ksize_half) {
+    return fb_window_launch<5, 1, false>(ctx, src5, dst5, nullptr, nullptr, rows, cols, nullptr, ksize_half);
+}
+extern "C" int ofri_fb_window5_update_flow(ofri_ctx *ctx, const float *M5, float *flowx, float *flowy, int rows, int cols,
+                                           const float *half_taps_host, int ksize_half, int box) {
+    if (box) return fb_window_launch<5, 1, true>(ctx, M5, nullptr, flowx, flowy, rows, cols, nullptr, ksize_half);
+    return fb_window_launch<5, 0, true>(ctx, M5, nullptr, flowx, flowy, rows, cols, half_taps_host, ksize_half);
+}
+
+// ---- updateMatrices (.cl:256-348) -------------------------------------------------------------------
+__constant__ float c_fb_border[6] = {0.14f, 0.14f, 0.4472f, 0.4472f, 0.4472f, 1.f};
+
+__global__ void k_fb_update_matrices(const float *__restrict__ flowx, const float *__restrict__ flowy,
+                                     const float *__restrict__ R0, const float *__restrict__ R1, float *__restrict__ M,
+                                     int H, int W) {
+    int x = blockIdx.x * blockDim.x + threadIdx.x;
+    int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= W || y >= H) return;
+    const size_t P = (size_t)H * W, o = (size_t)y * W + x;
+    float dx = flowx[o], dy = flowy[o];
+    float fx = x + dx, fy = y + dy;
+    // convert_int(floor(.)): saturate so that absurd displacements stay "outside" instead of wrapping
+    float flx = floorf(fx), fly = floorf(fy);
+    int x1 = (int)fminf(fmaxf(flx, -1e9f), 1e9f), y1 = (int)fminf(fmaxf(fly, -1e9f), 1e9f);
+    fx -= x1;
+    fy -= y1;
+    float r2, r3, r4, r5, r6;
+    if (x1 >= 0 && y1 >= 0 && x1 < W - 1 && y1 < H - 1) {
+        float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
+        size_t q = (size_t)y1 * W + x1;
+        const float *p = R1;
+        r2 = a00 * p[q] + a01 * p[q + 1] + a10 * p[q + W] + a11 * p[q + W + 1]; p += P;
+        r3 = a00 * p[q] + a01 * p[q + 1] + a10 * p[q + W] + a11 * p[q + W + 1]; p += P;
+        r4 = a00 * p[q] + a01 * p[q + 1] + a10 * p[q + W] + a11 * p[q + W + 1]; p += P;
+        r5 = a00 * p[q] + a01 * p[q + 1] + a10 * p[q + W] + a11 * p[q + W + 1]; p += P;
+        r6 = a00 * p[q] + a01 * p[q + 1] + a10 * p[q + W] + a11 * p[q + W + 1];
+        r4 = (R0[2 * P + o] + r4) * 0.5f;
+        r5 = (R0[3 * P + o] + r5) * 0.5f;
+        r6 = (R0[4 * P + o] + r6) * 0.25f;
+    } else {
+        r2 = r3 = 0.f;
+        r4 = R0[2 * P + o];
+        r5 = R0[3 * P + o];
+        r6 = R0[4 * P + o] * 0.5f;
+    }
+    r2 = (R0[o] - r2) * 0.5f;
+    r3 = (R0[P + o] - r3) * 0.5f;
+    r2 += r4 * dy + r6 * dx;
+    r3 += r6 * dy + r5 * dx;
+    float scale = c_fb_border[min(x, 5)] * c_fb_border[min(y, 5)] * c_fb_border[min(W - x - 1, 5)] * c_fb_border[min(H - y - 1, 5)];
+    r2 *= scale; r3 *= scale; r4 *= scale; r5 *= scale; r6 *= scale;
+    M[o] = r4 * r4 + r6 * r6;
+    M[P + o] = (r4 + r5) * r6;
+    M[2 * P + o] = r5 * r5 + r6 * r6;
+    M[3 * P + o] = r4 * r2 + r6 * r3;
+    M[4 * P + o] = r6 * r2 + r5 * r3;
+}
+
+extern "C" int ofri_fb_update_matrices(ofri_ctx *ctx, const float *flowx, const float *flowy, const float *R0,
+                                       const float *R1, float *M, int rows, int cols) {
+    OFRI_TRY(ofri_check_ctx(ctx));
+    OFRI_REQUIRE(flowx && flowy && R0 && R1 && M, "null pointer");
+    OFRI_REQUIRE(rows > 0 && cols > 0, "bad shape");
+    dim3 b(64, 4), g(ceil_div(cols, 64), ceil_div(rows, 4));
+    k_fb_update_matrices<<<g, b, 0, ctx->stream>>>(flowx, flowy, R0, R1, M, rows, cols);
+    OFRI_LAUNCH_CHECK();
+    return OFRI_OK;
+}
+
+// ---- updateFlow (.cl:408-429) -----------------------------------------------------------------------
+__global__ void k_fb_update_flow(const float *__restrict__ M, float *__restrict__ flowx, float *__restrict__ flowy, size_t P) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, st = (size_t)gridDim.x * blockDim.x;
+    for (; i < P; i += st) {
+        float g11 = M[i], g12 = M[P + i], g22 = M[2 * P + i], h1 = M[3 * P + i], h2 = M[4 * P + i];
+        float detInv = 1.f / (g11 * g22 - g12 * g12 + 1e-3f);
+        flowx[i] = (g11 * h2 - g12 * h1) * detInv;
+        flowy[i] = (g22 * h1 - g12 * h2) * detInv;
+    }
+}
+extern "C" int ofri_fb_update_flow(ofri_ctx *ctx, const float *M, float *flowx, float *flowy, int rows, int cols) {
+    OFRI_TRY(ofri_check_ctx(ctx));
+    OFRI_REQUIRE(M && flowx && flowy, "null pointer");
+    OFRI_REQUIRE(rows > 0 && cols > 0, "bad shape");
+    size_t P = (size_t)rows * cols, g = (P + 255) / 256;
+    if (g > 4096) g = 4096;
+    k_fb_update_flow<<<(int)g, 256, 0, ctx->stream>>>(M, flowx, flowy, P);
+    OFRI_LAUNCH_CHECK();
+    return OFRI_OK;
+}

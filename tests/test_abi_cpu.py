@@ -70,3 +70,27 @@ def test_synthetic_pair_is_deterministic_and_piv_like():
     assert a.dtype == np.uint8 and a.shape == (128, 160) and a.max() > 100 and 0.2 < (a > 0).mean() < 0.7
     u = poiseuille_u(128)
     assert abs(u[0]) < 1e-12 and abs(u.min() + 4.0) < 1e-3
+
+
+def test_farneback_host_tables_match_reference_fixtures():
+    """Host-side constant tables of the Farneback adapter need no GPU; build one without a context."""
+    from conftest import load_gold
+    from GaussianKernelBitExact import getGaussianKernelBitExact
+    import Farneback_PyCL as FB
+    f = load_gold("farneback_tables")
+    for n, s in ((3, 0), (3, 0.5), (5, 0), (33, 4.95), (33, 16.5 * 0.3), (7, 1.2), (9, 0)):
+        tot, k = getGaussianKernelBitExact(n, s)
+        np.testing.assert_array_equal(np.float64(k), f["bitexact_%d_%g" % (n, s)])
+    for n, s in ((7, 1.5), (5, 1.1), (5, 1.2), (7, 0.0)):
+        o = FB.Farneback_PyCL.__new__(FB.Farneback_PyCL)
+        o.polyN, o.polySigma = n, s
+        for i, a in enumerate(o.FarnebackPrepareGaussian()):
+            np.testing.assert_array_equal(np.asarray(a), f["prep_%d_%g_%d" % (n, s, i)])
+    o = FB.Farneback_PyCL.__new__(FB.Farneback_PyCL)
+    o.polyN, o.polySigma = 7, 1.5
+    o.setPolynomialExpansionConsts()
+    assert o.matrixG.shape == (1, 8) and o.matrixIG.dtype == np.float32
+    o.setGaussianBlurKernel(33, 33 / 2 * 0.3)
+    np.testing.assert_array_equal(o.matrixGKernel[0], np.float32(f["bitexact_33_4.95"])[16:])
+    with pytest.raises(Exception):
+        FB.Farneback_PyCL(windowSize=32)

@@ -316,3 +316,80 @@ def test_driver_hs_plus_liushen_and_ls_main(ctx, pair):
     r1 = _driver_case("hs_L2_ls", *flow(I0, I1, 3.4, A([21, 45], 100), 2, 1, 0.48, LS(5)))
     r2 = _driver_case("ls_main_L2", *flow(I0[:256, :256].copy(), I1[:256, :256].copy(), 3.4, LS(0.1), 2, 1, None, None, True, True, True, True))
     print("driver rel L2 vs reference: hs_L2_ls", r1, "ls_main_L2", r2)
+
+
+# ------------------------------------------------------------------------------ Farneback
+# The reference's OpenCL kernels cannot be executed where the fixtures were made (no OpenCL device), so
+# these compare against the CPU restatement of the kernel text: parity unpinned by reference outputs.
+def _fb_inputs(shape, seed):
+    rng = np.random.default_rng(seed)
+    from piv_synth import synth_piv
+    a, b = synth_piv(shape[0], shape[1], seed=seed)
+    return a.astype(np.float32), b.astype(np.float32), rng
+
+
+@pytest.mark.parametrize("shape", [(64, 64), (37, 91), (130, 70)])
+def test_farneback_kernels_bit_exact_vs_oracle(ctx, shape):
+    from Farneback_PyCL import Farneback_PyCL
+    from oracle import farneback as fb
+    a, b, rng = _fb_inputs(shape, 11)
+    H, W = shape
+    for polyN, sig in ((7, 1.5), (5, 1.1)):
+        ad = Farneback_PyCL(polyN=polyN, polySigma=sig)
+        ad.setPolynomialExpansionConsts()
+        g, xg, xxg, i0, i1, i2, i3 = fb.prepare_gaussian(polyN, sig)
+        ig = np.array([i0, i1, i2, i3]).astype(np.float32)
+        RA = ad.polynomialExpansion(a, np.zeros((5 * H, W), np.float32))
+        np.testing.assert_array_equal(RA, fb.poly_expansion(a, polyN, g[polyN:], xg[polyN:], xxg[polyN:], ig))
+    RB = ad.polynomialExpansion(b, np.zeros((5 * H, W), np.float32))
+    # single-plane blur with the 3-tap and a wide kernel (wider than the image for the small shapes)
+    for n in (3, 9, 33):
+        ad.setGaussianBlurKernel(n, 0)
+        want = fb.gaussian_blur(a, fb.blur_taps(n, 0), n // 2)
+        np.testing.assert_array_equal(ad.gaussianBlur(a, n / 2, np.zeros_like(a)), want)
+    fx = (2.0 * rng.standard_normal(shape)).astype(np.float32); fy = (2.0 * rng.standard_normal(shape)).astype(np.float32)
+    fx[0, 0] = -50.0; fy[-1, -1] = 1e6                       # far outside: fallback branch
+    M = ad.updateMatrices(fx, fy, RA, RB, np.zeros((5 * H, W), np.float32))
+    Mo = fb.update_matrices(fx, fy, RA, RB)
+    np.testing.assert_array_equal(M, Mo)
+    ad.setGaussianBlurKernel(33, 33 / 2 * 0.3)
+    Mb = ad.gaussianBlur5(M, 33 / 2, np.zeros_like(M))
+    Mbo = fb.gaussian_blur5(Mo, fb.blur_taps(33, 4.95), 16)
+    np.testing.assert_array_equal(Mb, Mbo)
+    np.testing.assert_array_equal(ad.boxFilter5(M, 33 / 2, np.zeros_like(M)), fb.box_filter5(Mo, 16))
+    ux, uy = ad.updateFlow(Mb, np.zeros_like(a), np.zeros_like(a))
+    uxo, uyo = fb.update_flow(Mbo)
+    np.testing.assert_array_equal(ux, uxo); np.testing.assert_array_equal(uy, uyo)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(useGaussian=False, windowSize=15, Niters=3, polyN=5, polySigma=1.1),
+                                dict(pyramidalLevels=3)])
+def test_farneback_compute_vs_oracle(ctx, kw):
+    from Farneback_PyCL import Farneback_PyCL
+    from oracle import farneback as fb
+    a, b, rng = _fb_inputs((160, 192), 5)
+    U0 = (0.3 * rng.standard_normal(a.shape)).astype(np.float32); V0 = (0.3 * rng.standard_normal(a.shape)).astype(np.float32)
+    U, V, err = Farneback_PyCL(**kw).compute(a, b, U0.copy(), V0.copy())
+    Ur, Vr, _ = fb.FarnebackAdapter(**kw).compute(a, b, U0.copy(), V0.copy())
+    assert err == 'Unknown'
+    r = flow_rel(U, V, Ur, Vr)
+    print("farneback", kw, "rel L2 vs oracle", r)
+    assert r < 1e-5
+
+
+def test_farneback_in_driver_and_with_liushen(ctx, pair):
+    from Farneback_PyCL import Farneback_PyCL
+    from PhysicsBasedOpticalFlowLiuShen import LiuShenOpticalFlowAlgoAdapter as LS
+    from GenericPyramidalOpticalFlow import genericPyramidalOpticalFlow as flow
+    from oracle import farneback as fb, liushen, pyramid
+    I0, I1 = pair[0][:256, :256].copy(), pair[1][:256, :256].copy()
+    U, V = flow(I0, I1, 0.0, Farneback_PyCL(), 2, 1, None)
+    Ur, Vr = pyramid.pyramidal_flow(I0.copy(), I1.copy(), 0.0, fb.FarnebackAdapter(), 2, 1, None)
+    r1 = flow_rel(U, V, Ur, Vr)
+    U, V = flow(I0, I1, 0.0, Farneback_PyCL(), 2, 1, 0.48, LS(10))
+    Ur, Vr = pyramid.pyramidal_flow(I0.copy(), I1.copy(), 0.0, fb.FarnebackAdapter(), 2, 1, 0.48, liushen.LiuShenAdapter(10))
+    r2 = flow_rel(U, V, Ur, Vr)
+    print("driver farneback rel L2 vs oracle", r1, "farneback + liu-shen", r2)
+    assert r1 < 1e-4 and r2 < 1e-4
+    # physical sanity on the bundled Poiseuille pair: flow in -x, strongest near the centre rows
+    assert U[100:156, 40:216].mean() < -1.0

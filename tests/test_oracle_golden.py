@@ -147,3 +147,33 @@ def test_driver_hs_plus_liushen(pair):
     I0, I1 = pair
     _check_driver("hs_L2_ls", *pyramid.pyramidal_flow(I0.copy(), I1.copy(), 3.4, hs.HSAdapter([21, 45], 100), 2, 1, 0.48,
                                                      liushen.LiuShenAdapter(5)))
+
+
+def test_farneback_host_tables():
+    from oracle import farneback as fb
+    f = load_gold("farneback_tables")
+    for n, s in ((3, 0), (3, 0.5), (5, 0), (33, 4.95), (33, 16.5 * 0.3), (7, 1.2), (9, 0)):
+        k = fb.bitexact_kernel(n, s)
+        np.testing.assert_array_equal(k, f["bitexact_%d_%g" % (n, s)])
+        np.testing.assert_array_equal(np.float32(k), f["bitexact_f32_%d_%g" % (n, s)])
+    for n, s in ((7, 1.5), (5, 1.1), (5, 1.2), (7, 0.0)):
+        r = fb.prepare_gaussian(n, s)
+        for i, a in enumerate(r):
+            np.testing.assert_array_equal(np.asarray(a), f["prep_%d_%g_%d" % (n, s, i)])
+
+
+def test_farneback_oracle_recovers_poiseuille_profile():
+    """No reference output exists for the OpenCL kernels (parity unpinned); the restatement must at least
+    recover the known displacement field of a synthetic pair: u(y) parabolic in -x, v ~ 0."""
+    from oracle import farneback as fb
+    import sys, os
+    from piv_synth import synth_piv, poiseuille_u
+    a, b = synth_piv(128, 128, seed=2)
+    a, b = a.astype(np.float32), b.astype(np.float32)
+    z = np.zeros_like(a)
+    U, V, err = fb.FarnebackAdapter().compute(a, b, z, z.copy())
+    assert err == 'Unknown' and U.dtype == np.float32
+    prof = U[24:104, 24:104].mean(axis=1)
+    want = poiseuille_u(128)[24:104]
+    assert np.abs(prof - want).max() < 0.6
+    assert abs(V[24:104, 24:104].mean()) < 0.2
