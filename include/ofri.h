@@ -141,6 +141,16 @@ int ofri_fb_update_flow(ofri_ctx *ctx, const float *M, float *flowx, float *flow
 int ofri_fb_window5_update_flow(ofri_ctx *ctx, const float *M5, float *flowx, float *flowy, int rows,
                                 int cols, const float *half_taps_host, int ksize_half, int box);
 
+/* ---- dense Lucas-Kanade ----------------------------------------------------------------------------- */
+/* lkDense (src/pyrlkDenseLargeW.cl:304-669) as launched by denseLucasKanade_PyCl.compute
+ * (src/denseLucasKanade_PyCL.py:113-169): (2*half_window+1)^2 window (at most 32x32), Scharr
+ * gradients of im1, up to niter Newton steps per pixel with im2 sampled bilinearly (clamp to edge),
+ * step tolerance 0.01 px.  asym_* are the vorticity-enhancement window flags (:75-92; 0 when off).
+ * Pixels whose window has a singular structure tensor keep their input displacement. */
+int ofri_lk_compute(ofri_ctx *ctx, const float *im1, const float *im2, const float *U_in,
+                    const float *V_in, float *U_out, float *V_out, int rows, int cols, int niter,
+                    int half_window, int asym_left, int asym_right, int asym_top, int asym_bottom);
+
 /* ---- pyramid glue --------------------------------------------------------------------------- */
 /* imresize (src/GenericPyramidalOpticalFlow.py:67-68): Pillow's scale-aware bicubic (a = -0.5) on
  * float32: horizontal then vertical pass, float64 accumulation, float32 intermediate. */

@@ -393,3 +393,50 @@ def test_farneback_in_driver_and_with_liushen(ctx, pair):
     assert r1 < 1e-4 and r2 < 1e-4
     # physical sanity on the bundled Poiseuille pair: flow in -x, strongest near the centre rows
     assert U[100:156, 40:216].mean() < -1.0
+
+
+# ------------------------------------------------------------------------------ dense Lucas-Kanade
+# Parity unpinned by reference outputs (the kernel needs an OpenCL image sampler); compared against the
+# CPU restatement of the kernel text, which uses the same exact float32 bilinear sampling.
+@pytest.mark.parametrize("shape,hw,nit", [((48, 56), 13, 5), ((33, 41), 6, 3), ((40, 40), 15, 2)])
+def test_lk_vs_oracle(ctx, shape, hw, nit):
+    from denseLucasKanade_PyCL import denseLucasKanade_PyCl
+    from oracle import lk
+    from piv_synth import synth_piv
+    a, b = synth_piv(shape[0], shape[1], seed=4, peak=-2.0)
+    a, b = a.astype(np.float32), b.astype(np.float32)
+    rng = np.random.default_rng(9)
+    U0 = (0.2 * rng.standard_normal(shape)).astype(np.float32); V0 = (0.2 * rng.standard_normal(shape)).astype(np.float32)
+    a[:6, :20] = 0.0                       # a flat corner: singular structure tensor only where the window is empty
+    U0[5, 7] = 500.0                       # a start point far outside the image: the loop must bail out
+    U, V, e = denseLucasKanade_PyCl(Niter=nit, halfWindow=hw).compute(a, b, U0.copy(), V0.copy())
+    Ur, Vr = lk.lk_dense(a, b, U0, V0, nit, hw)
+    assert e is True and U.dtype == np.float32 and U.shape == shape
+    bad = (np.abs(U - Ur) > 1e-4) | (np.abs(V - Vr) > 1e-4)
+    r = flow_rel(U, V, Ur, Vr)
+    print("lk", shape, hw, nit, "rel L2 vs oracle", r, "pixels off by >1e-4:", int(bad.sum()))
+    assert r < 1e-5 and bad.mean() < 1e-3
+
+
+def test_lk_asymmetric_windows_and_driver(ctx, pair):
+    from denseLucasKanade_PyCL import denseLucasKanade_PyCl
+    from GenericPyramidalOpticalFlow import genericPyramidalOpticalFlow as flow
+    from oracle import lk, pyramid
+    I0, I1 = pair[0][200:264, 100:180].copy(), pair[1][200:264, 100:180].copy()
+    z = np.zeros_like(I0)
+    ad = denseLucasKanade_PyCl(enableVorticityEnhancement=True)
+    shear = np.fromfunction(lambda y, x: 0.05 * y, I0.shape).astype(np.float32)      # dU/dy > 0: positive "omega"
+    assert ad.evaluateVorticityEnhancement(shear, z) == lk.vorticity_config(shear, z, True) == [1, 0, 0, 1]
+    assert ad.evaluateVorticityEnhancement(-shear, z) == lk.vorticity_config(-shear, z, True) == [0, 1, 0, 1]
+    assert ad.evaluateVorticityEnhancement(z, z) == [0, 0, 0, 0]
+    for cfg in ([1, 0, 0, 1], [0, 1, 0, 1]):
+        Un, Vn, _ = ad._run(ctx.upload(I0), ctx.upload(I1), ctx.upload(z), ctx.upload(z), cfg)
+        Ur, Vr = lk.lk_dense(I0, I1, z, z, 5, 13, cfg)
+        assert flow_rel(Un.numpy(), Vn.numpy(), Ur, Vr) < 1e-5
+    # through the pyramid driver with the adapter's defaults (no warping, final level not rescaled)
+    J0, J1 = pair[0][128:256, 128:256].copy(), pair[1][128:256, 128:256].copy()
+    U, V = flow(J0, J1, 2.0, denseLucasKanade_PyCl(), 2, 1, None)
+    Ur, Vr = pyramid.pyramidal_flow(J0.copy(), J1.copy(), 2.0, lk.DenseLKAdapter(), 2, 1, None)
+    r = flow_rel(U, V, Ur, Vr)
+    print("driver dense LK rel L2 vs oracle", r)
+    assert r < 1e-4

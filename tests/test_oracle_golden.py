@@ -177,3 +177,20 @@ def test_farneback_oracle_recovers_poiseuille_profile():
     want = poiseuille_u(128)[24:104]
     assert np.abs(prof - want).max() < 0.6
     assert abs(V[24:104, 24:104].mean()) < 0.2
+
+
+def test_lk_oracle_recovers_uniform_shift():
+    """Parity unpinned (no OpenCL device for the reference kernel): the restatement must at least find a
+    known sub-pixel translation of a textured image."""
+    from oracle import lk
+    rng = np.random.default_rng(0)
+    base = rng.uniform(0, 255, (70, 80)).astype(np.float32)
+    from scipy.ndimage import gaussian_filter, shift
+    base = gaussian_filter(base, 1.5).astype(np.float32)
+    moved = shift(base, (0.6, -1.3), order=3, mode='nearest').astype(np.float32)       # content moves by (+0.6 rows, -1.3 cols)
+    z = np.zeros_like(base)
+    U, V = lk.lk_dense(base[:40, :44], moved[:40, :44], z[:40, :44], z[:40, :44], 5, 13)
+    assert abs(U[14:26, 14:30].mean() + 1.3) < 0.1 and abs(V[14:26, 14:30].mean() - 0.6) < 0.1
+    flat = np.full((20, 20), 3.0, np.float32)
+    U, V = lk.lk_dense(flat, flat, z[:20, :20] + 0.25, z[:20, :20], 5, 13)
+    assert (U == 0.25).all() and (V == 0).all()                                          # singular windows keep their input
