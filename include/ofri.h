@@ -172,6 +172,10 @@ int ofri_warp_coords(ofri_ctx *ctx, const float *img, const float *cy, const flo
  * (y + half_sign*V/2, x + half_sign*U/2); half_sign = -1 for image 1, +1 for image 2. */
 int ofri_warp_flow(ofri_ctx *ctx, const float *img, const float *U, const float *V,
                    float half_sign, float *out, int rows, int cols);
+/* both warps of updateNextPyramidalLevel (:200-201) in one pass: out1 = im1 at (y - V/2, x - U/2),
+ * out2 = im2 at (y + V/2, x + U/2). */
+int ofri_warp_pair(ofri_ctx *ctx, const float *im1, const float *im2, const float *U, const float *V,
+                   float *out1, float *out2, int rows, int cols);
 /* acc += x  (Uaccum += U, src/GenericPyramidalOpticalFlow.py:413-414);  y *= s */
 int ofri_add_inplace(ofri_ctx *ctx, float *acc, const float *x, size_t n);
 int ofri_scale_inplace(ofri_ctx *ctx, float *y, float s, size_t n);

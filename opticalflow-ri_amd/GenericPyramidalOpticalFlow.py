@@ -67,8 +67,8 @@ def next_level_device(im1, prev_shape, im2, Uacc, Vacc, warping=True, biLinear=T
         raise NotImplementedError("biLinear=False (optical-flow-equation warp of the reference, "
                                   "GenericPyramidalOpticalFlow.py:204-221) is not implemented on the GPU path")
     _say('Warping: BiLinear')
-    w1 = warp_flow_device(im1, us, vs, -1.0)
-    w2 = warp_flow_device(im2, us, vs, +1.0)
+    w1, w2 = ctx.empty((H, W)), ctx.empty((H, W))
+    _ofri.check(_ofri.lib().ofri_warp_pair(ctx.handle, im1.ptr, im2.ptr, us.ptr, vs.ptr, w1.ptr, w2.ptr, H, W))
     return w1, w2, us, vs, ctx.zeros((H, W)), ctx.zeros((H, W))
 
 

@@ -66,6 +66,7 @@ _PROTOS = {
     "ofri_spline_upsample": ([_vp, _vp, _i, _i, _vp, _i, _i, _f], _i),
     "ofri_warp_coords": ([_vp, _vp, _vp, _vp, _vp, _i, _i], _i),
     "ofri_warp_flow": ([_vp, _vp, _vp, _vp, _f, _vp, _i, _i], _i),
+    "ofri_warp_pair": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i], _i),
     "ofri_add_inplace": ([_vp, _vp, _vp, _sz], _i),
     "ofri_scale_inplace": ([_vp, _vp, _f, _sz], _i),
     "ofri_norm_diff": ([_vp, _vp, _vp, _sz, C.POINTER(_d)], _i),

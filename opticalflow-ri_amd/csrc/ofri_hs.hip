@@ -166,13 +166,71 @@ static int hs_sweep_launch(ofri_ctx *ctx, const float *U, const float *V, const 
     return OFRI_OK;
 }
 
-int ofri_hs_fused_passes(ofri_ctx *ctx, float *&cu, float *&cv, float *&nu, float *&nv, const float *fx,
-                         const float *fy, const float *ft, float a2, int &remaining, int &launches, int H, int W);
+bool ofri_hs_fused_ok(const void *const *ptrs, int nptrs, int H, int W);
+int ofri_hs_fused_max_sweeps(void);
+int ofri_hs_fused_launch(ofri_ctx *ctx, const float *su, const float *sv, float *du, float *dv, const float *fx,
+                         const float *fy, const float *ft, float a2, int T, int H, int W);
 
 extern "C" int ofri_hs_set_fuse(ofri_ctx *ctx, int sweeps_per_launch) {
     OFRI_REQUIRE(ctx, "null context");
     OFRI_REQUIRE(sweeps_per_launch >= -1 && sweeps_per_launch <= 64, "sweeps_per_launch out of range");
     ctx->hs_fuse = sweeps_per_launch;
+    return OFRI_OK;
+}
+
+// niter sweeps from (Uin, Vin) into (Uout, Vout); Uin/Vin may alias Uout/Vout.  Launches ping-pong between
+// the output planes and two pooled scratch planes, arranged so that the last launch lands in the output.
+static int hs_iterate_io(ofri_ctx *ctx, const float *Uin, const float *Vin, float *Uout, float *Vout, const float *fx,
+                         const float *fy, const float *ft, float alpha, int niter, int rows, int cols) {
+    const size_t bytes = (size_t)rows * cols * sizeof(float);
+    if (niter == 0) {
+        if (Uin != Uout) OFRI_HIP(hipMemcpyAsync(Uout, Uin, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+        if (Vin != Vout) OFRI_HIP(hipMemcpyAsync(Vout, Vin, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+        return OFRI_OK;
+    }
+    PoolBuf tu(ctx), tv(ctx);
+    OFRI_TRY(tu.get(bytes));
+    OFRI_TRY(tv.get(bytes));
+    const float a2 = alpha * alpha;         // alpha is a float32 in the reference's compiled signature
+    const bool exact = ctx->hs_fuse == -1;  // -1: bit-exact restatement of scipy's float64 accumulation
+    const void *ptrs[9] = {Uin, Vin, Uout, Vout, fx, fy, ft, tu.p, tv.p};
+    const bool fused = !exact && ctx->hs_fuse != 1 && ofri_hs_fused_ok(ptrs, 9, rows, cols);
+    int Tmax = 1;
+    if (fused) {
+        Tmax = ofri_hs_fused_max_sweeps();
+        if (ctx->hs_fuse > 1 && ctx->hs_fuse < Tmax) Tmax = ctx->hs_fuse;
+    }
+    const int L = (niter + Tmax - 1) / Tmax;
+    const bool inplace = (Uin == Uout) || (Vin == Vout) || (Uin == Vout) || (Vin == Uout);
+    // launch k writes the output planes when (L-1-k) is even; an in-place call whose first launch would
+    // overwrite its own source runs one launch more through the scratch planes instead (final copy)
+    const bool detour = inplace && ((L - 1) % 2 == 0);
+    ofri_ctx::ProfRec rec{};
+    if (ctx->prof) {
+        OFRI_HIP(hipEventCreate(&rec.a)); OFRI_HIP(hipEventCreate(&rec.b));
+        OFRI_HIP(hipEventRecord(rec.a, ctx->stream));
+    }
+    const float *su = Uin, *sv = Vin;
+    int remaining = niter;
+    for (int k = 0; k < L; ++k) {
+        const bool to_out = detour ? ((L - k) % 2 == 0) : ((L - 1 - k) % 2 == 0);
+        float *du = to_out ? Uout : tu.as<float>(), *dv = to_out ? Vout : tv.as<float>();
+        const int T = remaining < Tmax ? remaining : Tmax;
+        if (fused) OFRI_TRY(ofri_hs_fused_launch(ctx, su, sv, du, dv, fx, fy, ft, a2, T, rows, cols));
+        else if (exact) OFRI_TRY(hs_sweep_launch<true>(ctx, su, sv, fx, fy, ft, du, dv, a2, rows, cols));
+        else OFRI_TRY(hs_sweep_launch<false>(ctx, su, sv, fx, fy, ft, du, dv, a2, rows, cols));
+        su = du; sv = dv;
+        remaining -= T;
+    }
+    if (ctx->prof) {
+        OFRI_HIP(hipEventRecord(rec.b, ctx->stream));
+        rec.rows = rows; rec.cols = cols; rec.launches = L; rec.sweeps = niter;
+        ctx->prof_recs.push_back(rec);
+    }
+    if (su != Uout) {
+        OFRI_HIP(hipMemcpyAsync(Uout, su, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+        OFRI_HIP(hipMemcpyAsync(Vout, sv, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    }
     return OFRI_OK;
 }
 
@@ -182,38 +240,7 @@ extern "C" int ofri_hs_iterate(ofri_ctx *ctx, float *U, float *V, const float *f
     OFRI_REQUIRE(U && V && fx && fy && ft, "null pointer");
     OFRI_REQUIRE(rows > 0 && cols > 0, "bad shape %d x %d", rows, cols);
     OFRI_REQUIRE(niter >= 0, "niter < 0");
-    if (niter == 0) return OFRI_OK;
-    size_t bytes = (size_t)rows * cols * sizeof(float);
-    PoolBuf tu(ctx), tv(ctx);
-    OFRI_TRY(tu.get(bytes));
-    OFRI_TRY(tv.get(bytes));
-    float a2 = alpha * alpha;            // alpha is a float32 in the reference's compiled signature
-    float *cu = U, *cv = V, *nu = tu.as<float>(), *nv = tv.as<float>();
-    int remaining = niter, launches = 0;
-    ofri_ctx::ProfRec rec{};
-    if (ctx->prof) {
-        OFRI_HIP(hipEventCreate(&rec.a)); OFRI_HIP(hipEventCreate(&rec.b));
-        OFRI_HIP(hipEventRecord(rec.a, ctx->stream));
-    }
-    const bool exact = ctx->hs_fuse == -1;  // -1: bit-exact restatement of scipy's float64 accumulation
-    if (!exact && ctx->hs_fuse != 1)
-        OFRI_TRY(ofri_hs_fused_passes(ctx, cu, cv, nu, nv, fx, fy, ft, a2, remaining, launches, rows, cols));
-    for (; remaining > 0; --remaining, ++launches) {
-        if (exact) OFRI_TRY(hs_sweep_launch<true>(ctx, cu, cv, fx, fy, ft, nu, nv, a2, rows, cols));
-        else       OFRI_TRY(hs_sweep_launch<false>(ctx, cu, cv, fx, fy, ft, nu, nv, a2, rows, cols));
-        float *t = cu; cu = nu; nu = t;
-        t = cv; cv = nv; nv = t;
-    }
-    if (ctx->prof) {
-        OFRI_HIP(hipEventRecord(rec.b, ctx->stream));
-        rec.rows = rows; rec.cols = cols; rec.launches = launches; rec.sweeps = niter;
-        ctx->prof_recs.push_back(rec);
-    }
-    if (cu != U) {
-        OFRI_HIP(hipMemcpyAsync(U, cu, bytes, hipMemcpyDeviceToDevice, ctx->stream));
-        OFRI_HIP(hipMemcpyAsync(V, cv, bytes, hipMemcpyDeviceToDevice, ctx->stream));
-    }
-    return OFRI_OK;
+    return hs_iterate_io(ctx, U, V, U, V, fx, fy, ft, alpha, niter, rows, cols);
 }
 
 extern "C" int ofri_hs_compute(ofri_ctx *ctx, const float *frame0, const float *frame1,
@@ -228,9 +255,7 @@ extern "C" int ofri_hs_compute(ofri_ctx *ctx, const float *frame0, const float *
     OFRI_TRY(fx.get(bytes)); OFRI_TRY(fy.get(bytes)); OFRI_TRY(ft.get(bytes));
     // HS(im2=frame0, im1=frame1) -> computeDerivatives(im1=frame1, im2=frame0)   (HornSchunck.py:37,73,84)
     OFRI_TRY(ofri_hs_derivs(ctx, frame1, frame0, fx.as<float>(), fy.as<float>(), ft.as<float>(), rows, cols));
-    OFRI_HIP(hipMemcpyAsync(U_out, U_in, bytes, hipMemcpyDeviceToDevice, ctx->stream));
-    OFRI_HIP(hipMemcpyAsync(V_out, V_in, bytes, hipMemcpyDeviceToDevice, ctx->stream));
-    OFRI_TRY(ofri_hs_iterate(ctx, U_out, V_out, fx.as<float>(), fy.as<float>(), ft.as<float>(), alpha, niter, rows, cols));
+    OFRI_TRY(hs_iterate_io(ctx, U_in, V_in, U_out, V_out, fx.as<float>(), fy.as<float>(), ft.as<float>(), alpha, niter, rows, cols));
     if (err_host) {
         OFRI_TRY(ofri_norm_diff_dev(ctx, U_out, U_in, n, 0));
         OFRI_TRY(ofri_norm_diff_dev(ctx, V_out, V_in, n, 1));

@@ -153,23 +153,19 @@ k_hs_fused(const float *__restrict__ U, const float *__restrict__ V, const float
     }
 }
 
-// Runs as many fused passes as fit and leaves the remainder (remaining) to the caller; swaps the
-// ping-pong pointers once per pass.
-int ofri_hs_fused_passes(ofri_ctx *ctx, float *&cu, float *&cv, float *&nu, float *&nv, const float *fx,
-                         const float *fy, const float *ft, float a2, int &remaining, int &launches, int H, int W) {
-    const bool aligned = ((((size_t)cu | (size_t)cv | (size_t)fx | (size_t)fy | (size_t)ft | (size_t)nu | (size_t)nv) & 15) == 0);
-    if (!aligned || (W & 3) || W < 16 || H < 16) return OFRI_OK;
-    int Tmax = ctx->hs_fuse > 1 ? ctx->hs_fuse : FT_HALO;
-    if (Tmax > FT_HALO) Tmax = FT_HALO;
+// The fused kernel needs 16-byte aligned planes, a width that is a multiple of 4 and at least 16 x 16 pixels.
+bool ofri_hs_fused_ok(const void *const *ptrs, int nptrs, int H, int W) {
+    size_t bits = 0;
+    for (int i = 0; i < nptrs; ++i) bits |= (size_t)ptrs[i];
+    return (bits & 15) == 0 && (W & 3) == 0 && W >= 16 && H >= 16;
+}
+int ofri_hs_fused_max_sweeps(void) { return FT_HALO; }
+
+// One launch: T <= FT_HALO sweeps from (su, sv) into (du, dv); source and destination must differ.
+int ofri_hs_fused_launch(ofri_ctx *ctx, const float *su, const float *sv, float *du, float *dv, const float *fx,
+                         const float *fy, const float *ft, float a2, int T, int H, int W) {
     const int tiles_x = ceil_div(W, FT_OX), tiles_y = ceil_div(H, FT_OY), ntiles = tiles_x * tiles_y;
-    while (remaining > 0) {
-        int T = remaining < Tmax ? remaining : Tmax;
-        k_hs_fused<<<ntiles, 256, 0, ctx->stream>>>(cu, cv, fx, fy, ft, nu, nv, a2, H, W, T, tiles_x, ntiles);
-        OFRI_LAUNCH_CHECK();
-        float *t = cu; cu = nu; nu = t;
-        t = cv; cv = nv; nv = t;
-        remaining -= T;
-        ++launches;
-    }
+    k_hs_fused<<<ntiles, 256, 0, ctx->stream>>>(su, sv, fx, fy, ft, du, dv, a2, H, W, T, tiles_x, ntiles);
+    OFRI_LAUNCH_CHECK();
     return OFRI_OK;
 }

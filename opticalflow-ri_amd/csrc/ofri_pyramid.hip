@@ -21,7 +21,7 @@ static double linear_w(double x) {
     return x < 1.0 ? 1.0 - x : 0.0;
 }
 
-struct ResampleTable { int ksize; const int *bounds; const double *w; };   // device pointers
+struct ResampleTable { int ksize, n_out; const int *bounds; const double *w; };   // device pointers; w is tap-major: w[tap*n_out + out]
 
 static int get_resample_table(ofri_ctx *ctx, int n_in, int n_out, int filter, ResampleTable *t) {
     const double support0 = filter == 0 ? 2.0 : 1.0;
@@ -40,15 +40,17 @@ static int get_resample_table(ofri_ctx *ctx, int n_in, int n_out, int filter, Re
             int lo = (int)(c - sup + 0.5); if (lo < 0) lo = 0;
             int hi = (int)(c + sup + 0.5); if (hi > n_in) hi = n_in;
             int cnt = hi - lo;
-            double tot = 0.0, *k = &w[(size_t)o * ksize];
+            double tot = 0.0;
+            std::vector<double> k(cnt > 0 ? cnt : 1);
             for (int x = 0; x < cnt; ++x) { k[x] = fw((x + lo - c + 0.5) * (1.0 / fs)); tot += k[x]; }
             if (tot != 0.0) for (int x = 0; x < cnt; ++x) k[x] /= tot;
+            for (int x = 0; x < cnt; ++x) w[(size_t)x * n_out + o] = k[x];
             bounds[2 * o] = lo; bounds[2 * o + 1] = cnt;
         }
         OFRI_TRY(ofri_cached_table(ctx, key + "b", bounds.data(), bounds.size() * sizeof(int), &pb));
         OFRI_TRY(ofri_cached_table(ctx, key + "w", w.data(), w.size() * sizeof(double), &pw));
     }
-    t->ksize = ksize; t->bounds = (const int *)pb; t->w = (const double *)pw;
+    t->ksize = ksize; t->n_out = n_out; t->bounds = (const int *)pb; t->w = (const double *)pw;
     return OFRI_OK;
 }
 
@@ -61,14 +63,15 @@ __global__ void k_resample(const float *__restrict__ in, int H_in, int W_in, flo
     if (x >= W_out || y >= H_out) return;
     int o = AXIS == 1 ? x : y;
     int lo = t.bounds[2 * o], cnt = t.bounds[2 * o + 1];
-    const double *k = t.w + (size_t)o * t.ksize;
+    const double *k = t.w + o;
+    const size_t ks = (size_t)t.n_out;
     double ss = 0.0;
     if (AXIS == 1) {
         const float *row = in + (size_t)y * W_in + lo;
-        for (int i = 0; i < cnt; ++i) ss = __dadd_rn(ss, __dmul_rn((double)row[i], k[i]));
+        for (int i = 0; i < cnt; ++i) ss = __dadd_rn(ss, __dmul_rn((double)row[i], k[i * ks]));
     } else {
         const float *col = in + (size_t)lo * W_in + x;
-        for (int i = 0; i < cnt; ++i) ss = __dadd_rn(ss, __dmul_rn((double)col[(size_t)i * W_in], k[i]));
+        for (int i = 0; i < cnt; ++i) ss = __dadd_rn(ss, __dmul_rn((double)col[(size_t)i * W_in], k[i * ks]));
     }
     out[(size_t)y * W_out + x] = (float)ss;
 }
@@ -384,6 +387,30 @@ __global__ void k_warp_flow(const float *__restrict__ img, const float *__restri
     float cy = (float)((double)y + (double)(sgn * (V[o] * 0.5f)));
     float cx = (float)((double)x + (double)(sgn * (U[o] * 0.5f)));
     out[o] = warp_sample(img, H, W, cy, cx);
+}
+
+// both images of the symmetric warp in one pass: the flow is read once
+__global__ void k_warp_pair(const float *__restrict__ im1, const float *__restrict__ im2, const float *__restrict__ U,
+                            const float *__restrict__ V, float *__restrict__ out1, float *__restrict__ out2, int H, int W) {
+    int x = blockIdx.x * blockDim.x + threadIdx.x;
+    int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= W || y >= H) return;
+    size_t o = (size_t)y * W + x;
+    float hu = U[o] * 0.5f, hv = V[o] * 0.5f;
+    out1[o] = warp_sample(im1, H, W, (float)((double)y + (double)(-hv)), (float)((double)x + (double)(-hu)));
+    out2[o] = warp_sample(im2, H, W, (float)((double)y + (double)hv), (float)((double)x + (double)hu));
+}
+
+extern "C" int ofri_warp_pair(ofri_ctx *ctx, const float *im1, const float *im2, const float *U, const float *V,
+                              float *out1, float *out2, int rows, int cols) {
+    OFRI_TRY(ofri_check_ctx(ctx));
+    OFRI_REQUIRE(im1 && im2 && U && V && out1 && out2, "null pointer");
+    OFRI_REQUIRE(out1 != im1 && out2 != im2 && out1 != out2 && out1 != im2 && out2 != im1, "aliased pointer");
+    OFRI_REQUIRE(rows > 0 && cols > 0, "bad shape");
+    dim3 b(64, 4), g(ceil_div(cols, 64), ceil_div(rows, 4));
+    k_warp_pair<<<g, b, 0, ctx->stream>>>(im1, im2, U, V, out1, out2, rows, cols);
+    OFRI_LAUNCH_CHECK();
+    return OFRI_OK;
 }
 
 extern "C" int ofri_warp_coords(ofri_ctx *ctx, const float *img, const float *cy, const float *cx,
