@@ -12,7 +12,8 @@ struct FbPoly { float g[8], xg[8], xxg[8], ig[4]; };
 // border index helpers of the reference (.cl:135-158): reflect-101 with a modulo guard
 __device__ __forceinline__ int fb_low(int y, int last) { return abs(y) % (last + 1); }
 __device__ __forceinline__ int fb_high(int y, int last) { return abs(last - abs(last - y)) % (last + 1); }
-__device__ __forceinline__ int fb_idx(int t, int last) { return fb_low(fb_high(t, last), last); }
+// in-range indices map to themselves under both helpers; only out-of-range ones pay for the modulo
+__device__ __forceinline__ int fb_idx(int t, int last) { return (unsigned)t <= (unsigned)last ? t : fb_low(fb_high(t, last), last); }
 
 // ---- polynomial expansion (.cl:72-133) -----------------------------------------------------------
 #define PE_TX 64
@@ -105,24 +106,26 @@ k_fb_window(const float *__restrict__ src, float *__restrict__ dst, float *__res
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
         const float *sp = src + p * P;
-        for (int i = tid; i < TH * TW; i += 256) {
-            int ly = i / TW, lx = i - ly * TW;
-            int y = by + ly - ksh, x = bx + lx - ksh;
-            if (MODE == 0) { y = fb_idx(y, H - 1); x = fb_idx(x, W - 1); }
-            else { y = clampi(y, 0, H - 1); x = clampi(x, 0, W - 1); }
-            tin[i] = sp[(size_t)y * W + x];
+        for (int ly = threadIdx.y; ly < TH; ly += 4) {
+            int y = by + ly - ksh;
+            y = MODE == 0 ? fb_idx(y, H - 1) : clampi(y, 0, H - 1);
+            for (int lx = threadIdx.x; lx < TW; lx += 64) {
+                int x = bx + lx - ksh;
+                x = MODE == 0 ? fb_idx(x, W - 1) : clampi(x, 0, W - 1);
+                tin[ly * TW + lx] = sp[(size_t)y * W + x];
+            }
         }
         __syncthreads();
-        for (int i = tid; i < BL_TY * TW; i += 256) {
-            int ly = i / TW, lx = i - ly * TW;
-            const float *c = tin + (size_t)(ly + ksh) * TW + lx;
-            float acc = MODE == 0 ? c[0] * taps.k[0] : c[0];
-            for (int j = 1; j <= ksh; ++j) {
-                float s = c[-j * TW] + c[j * TW];
-                acc += MODE == 0 ? s * taps.k[j] : s;
+        for (int ly = threadIdx.y; ly < BL_TY; ly += 4)
+            for (int lx = threadIdx.x; lx < TW; lx += 64) {
+                const float *c = tin + (size_t)(ly + ksh) * TW + lx;
+                float acc = MODE == 0 ? c[0] * taps.k[0] : c[0];
+                for (int j = 1; j <= ksh; ++j) {
+                    float s = c[-j * TW] + c[j * TW];
+                    acc += MODE == 0 ? s * taps.k[j] : s;
+                }
+                tv[ly * TW + lx] = acc;
             }
-            tv[i] = acc;
-        }
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -158,6 +161,110 @@ k_fb_window(const float *__restrict__ src, float *__restrict__ dst, float *__res
     }
 }
 
+// Same filter for the reference's default window (ksize_half = 16, windowSize 33), with register
+// windows: the vertical pass gives each thread 4 stacked outputs of one column (36 LDS reads for 4
+// results instead of 132), the horizontal pass 4 adjacent outputs of one row fetched as nine 16-byte LDS
+// reads.  Taps are applied in the reference's order (centre, then pairs outward), so results are
+// identical to k_fb_window.
+template <int NP, int MODE, bool FLOW>
+__global__ void __launch_bounds__(256)
+k_fb_window16(const float *__restrict__ src, float *__restrict__ dst, float *__restrict__ flowx, float *__restrict__ flowy,
+              int H, int W, FbTaps taps) {
+    constexpr int KSH = 16, TW = BL_TX + 2 * KSH, TH = BL_TY + 2 * KSH;      // 96 x 48
+    __shared__ float tin[TH][TW];
+    __shared__ __attribute__((aligned(16))) float tv[BL_TY][TW];
+    const int bx = blockIdx.x * BL_TX, by = blockIdx.y * BL_TY, tid = threadIdx.x;
+    const size_t P = (size_t)H * W;
+    const int ly = tid >> 4, xg = tid & 15;                                  // horizontal pass: row, group of 4 columns
+    float res[NP][4];
+    // this thread's 18 samples of a plane's 48 x 96 source tile: rows (tid>>5) + 8s, columns (tid&31) + 32q.
+    // All loads of a plane are issued together, and the next plane's are issued before the current
+    // plane is filtered, so their latency hides behind the arithmetic.
+    unsigned offs[18];          // the launcher guarantees rows*cols < 2^32
+#pragma unroll
+    for (int sidx = 0; sidx < 6; ++sidx) {
+        int y = by + (tid >> 5) + 8 * sidx - KSH;
+        y = MODE == 0 ? fb_idx(y, H - 1) : clampi(y, 0, H - 1);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            int x = bx + (tid & 31) + 32 * q - KSH;
+            x = MODE == 0 ? fb_idx(x, W - 1) : clampi(x, 0, W - 1);
+            offs[sidx * 3 + q] = (unsigned)y * (unsigned)W + (unsigned)x;
+        }
+    }
+    float pre[18];
+#pragma unroll
+    for (int e = 0; e < 18; ++e) pre[e] = src[offs[e]];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+#pragma unroll
+        for (int sidx = 0; sidx < 6; ++sidx)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) tin[(tid >> 5) + 8 * sidx][(tid & 31) + 32 * q] = pre[sidx * 3 + q];
+        __syncthreads();
+        if (p + 1 < NP) {
+            const float *sp = src + (size_t)(p + 1) * P;
+#pragma unroll
+            for (int e = 0; e < 18; ++e) pre[e] = sp[offs[e]];
+        }
+        for (int i = tid; i < (BL_TY / 4) * TW; i += 256) {
+            const int rg = i / TW, col = i - rg * TW;
+            float w[36];
+#pragma unroll
+            for (int t = 0; t < 36; ++t) w[t] = tin[rg * 4 + t][col];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float acc = MODE == 0 ? w[KSH + r] * taps.k[0] : w[KSH + r];
+#pragma unroll
+                for (int j = 1; j <= KSH; ++j) {
+                    float sm = w[KSH + r - j] + w[KSH + r + j];
+                    acc += MODE == 0 ? sm * taps.k[j] : sm;
+                }
+                tv[rg * 4 + r][col] = acc;
+            }
+        }
+        __syncthreads();
+        {
+            float c[36];
+            const float4 *row4 = reinterpret_cast<const float4 *>(&tv[ly][4 * xg]);
+#pragma unroll
+            for (int q = 0; q < 9; ++q) { float4 v = row4[q]; c[4 * q] = v.x; c[4 * q + 1] = v.y; c[4 * q + 2] = v.z; c[4 * q + 3] = v.w; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float acc = MODE == 0 ? c[KSH + k] * taps.k[0] : c[KSH + k];
+#pragma unroll
+                for (int i = 1; i <= KSH; ++i) {
+                    float sm = c[KSH + k - i] + c[KSH + k + i];
+                    acc += MODE == 0 ? sm * taps.k[i] : sm;
+                }
+                res[p][k] = acc;
+            }
+        }
+        // next plane: tin is rewritten before, tv after the barrier that follows the tin load
+    }
+    const float box_inv = 1.f / ((1 + 2 * KSH) * (1 + 2 * KSH));
+    const int y = by + ly, x0 = bx + 4 * xg;
+    if (y >= H) return;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int x = x0 + k;
+        if (x >= W) continue;
+        size_t o = (size_t)y * W + x;
+        float v[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) v[p] = MODE == 0 ? res[p][k] : res[p][k] * box_inv;
+        if (FLOW) {
+            float g11 = v[0], g12 = v[NP > 1 ? 1 : 0], g22 = v[NP > 2 ? 2 : 0], h1 = v[NP > 3 ? 3 : 0], h2 = v[NP > 4 ? 4 : 0];
+            float detInv = 1.f / (g11 * g22 - g12 * g12 + 1e-3f);
+            flowx[o] = (g11 * h2 - g12 * h1) * detInv;
+            flowy[o] = (g22 * h1 - g12 * h2) * detInv;
+        } else {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) dst[p * P + o] = v[p];
+        }
+    }
+}
+
 template <int NP, int MODE, bool FLOW>
 static int fb_window_launch(ofri_ctx *ctx, const float *src, float *dst, float *fx, float *fy, int rows, int cols,
                             const float *taps_host, int ksh) {
@@ -170,6 +277,12 @@ static int fb_window_launch(ofri_ctx *ctx, const float *src, float *dst, float *
     FbTaps t;
     memset(&t, 0, sizeof(t));
     if (MODE == 0) memcpy(t.k, taps_host, (ksh + 1) * sizeof(float));
+    if (ksh == 16 && (size_t)rows * cols < 0xffffffffull) {
+        dim3 g16(ceil_div(cols, BL_TX), ceil_div(rows, BL_TY));
+        k_fb_window16<NP, MODE, FLOW><<<g16, 256, 0, ctx->stream>>>(src, dst, fx, fy, rows, cols, t);
+        OFRI_LAUNCH_CHECK();
+        return OFRI_OK;
+    }
     size_t lds = ((size_t)(BL_TY + 2 * ksh) * (BL_TX + 2 * ksh) + (size_t)BL_TY * (BL_TX + 2 * ksh)) * sizeof(float);
     OFRI_REQUIRE(lds <= 160 * 1024, "window too large for LDS");
     auto kern = k_fb_window<NP, MODE, FLOW>;

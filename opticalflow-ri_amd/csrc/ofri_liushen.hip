@@ -105,10 +105,11 @@ __device__ inline double ls_wave_sum(double v) {
     return v;
 }
 
-// One sweep, 64x4 threads, one pixel per thread, u/v tile with a one-pixel apron staged in LDS.
-// Blocks exit at once when the stopping rule has already been met (state->done).
+// One sweep.  A 64x4-thread workgroup owns a 64 x 16 pixel tile (4 rows per thread); the u/v tile with a
+// one-pixel apron is staged in LDS.  Blocks exit at once when the stopping rule has already been met.
 #define LS_TX 64
-#define LS_TY 4
+#define LS_TY 16
+#define LS_RPT 4
 __global__ void __launch_bounds__(256)
 k_ls_sweep(const float *__restrict__ u, const float *__restrict__ v, float *__restrict__ un, float *__restrict__ vn,
            LsFields f, float h, int H, int W, const LsState *__restrict__ state, double *__restrict__ partials) {
@@ -124,23 +125,27 @@ k_ls_sweep(const float *__restrict__ u, const float *__restrict__ v, float *__re
         sv[ly][lx] = v[(size_t)gy * W + gx];
     }
     __syncthreads();
-    const int x = bx + threadIdx.x, y = by + threadIdx.y;
+    const int x = bx + threadIdx.x;
     double du2 = 0.0, dv2 = 0.0;
-    if (x < W && y < H) {
-        const int lx = threadIdx.x + 1, ly = threadIdx.y + 1;
-        size_t o = (size_t)y * W + x;
-        float a, b;
-        ls_point(su[ly - 1][lx], su[ly + 1][lx], su[ly][lx - 1], su[ly][lx + 1], su[ly - 1][lx - 1], su[ly - 1][lx + 1],
-                 su[ly + 1][lx - 1], su[ly + 1][lx + 1], su[ly][lx],
-                 sv[ly - 1][lx], sv[ly + 1][lx], sv[ly][lx - 1], sv[ly][lx + 1], sv[ly - 1][lx - 1], sv[ly - 1][lx + 1],
-                 sv[ly + 1][lx - 1], sv[ly + 1][lx + 1], sv[ly][lx],
-                 y > 0, y < H - 1, x > 0, x < W - 1,
-                 f.IIx[o], f.IIy[o], f.II[o], f.Ixt[o], f.Iyt[o], f.B11[o], f.B12[o], f.B22[o], h, a, b);
-        un[o] = a;
-        vn[o] = b;
-        double d1 = (double)__fsub_rn(a, su[ly][lx]), d2 = (double)__fsub_rn(b, sv[ly][lx]);
-        du2 = d1 * d1;
-        dv2 = d2 * d2;
+#pragma unroll
+    for (int r = 0; r < LS_RPT; ++r) {
+        const int y = by + threadIdx.y + 4 * r;
+        if (x < W && y < H) {
+            const int lx = threadIdx.x + 1, ly = threadIdx.y + 4 * r + 1;
+            size_t o = (size_t)y * W + x;
+            float a, b;
+            ls_point(su[ly - 1][lx], su[ly + 1][lx], su[ly][lx - 1], su[ly][lx + 1], su[ly - 1][lx - 1], su[ly - 1][lx + 1],
+                     su[ly + 1][lx - 1], su[ly + 1][lx + 1], su[ly][lx],
+                     sv[ly - 1][lx], sv[ly + 1][lx], sv[ly][lx - 1], sv[ly][lx + 1], sv[ly - 1][lx - 1], sv[ly - 1][lx + 1],
+                     sv[ly + 1][lx - 1], sv[ly + 1][lx + 1], sv[ly][lx],
+                     y > 0, y < H - 1, x > 0, x < W - 1,
+                     f.IIx[o], f.IIy[o], f.II[o], f.Ixt[o], f.Iyt[o], f.B11[o], f.B12[o], f.B22[o], h, a, b);
+            un[o] = a;
+            vn[o] = b;
+            double d1 = (double)__fsub_rn(a, su[ly][lx]), d2 = (double)__fsub_rn(b, sv[ly][lx]);
+            du2 += d1 * d1;
+            dv2 += d2 * d2;
+        }
     }
     du2 = ls_wave_sum(du2);
     dv2 = ls_wave_sum(dv2);
@@ -156,15 +161,18 @@ k_ls_sweep(const float *__restrict__ u, const float *__restrict__ v, float *__re
 // total_error = (|du| + |dv|) / (rows*cols); stop when it is <= tol (reference loop: while err > tol and k < maxnum)
 __global__ void k_ls_check(const double *__restrict__ partials, int nblocks, double inv_rc, double tol, LsState *state) {
     if (state->done) return;
-    __shared__ double sm[2][4];
+    __shared__ double sm[2][16];
     double a = 0.0, b = 0.0;
-    for (int i = threadIdx.x; i < nblocks; i += blockDim.x) { a += partials[2 * i]; b += partials[2 * i + 1]; }
+    const double2 *p2 = reinterpret_cast<const double2 *>(partials);
+    for (int i = threadIdx.x; i < nblocks; i += blockDim.x) { double2 q = p2[i]; a += q.x; b += q.y; }
     a = ls_wave_sum(a);
     b = ls_wave_sum(b);
     if ((threadIdx.x & 63) == 0) { sm[0][threadIdx.x >> 6] = a; sm[1][threadIdx.x >> 6] = b; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        double na = sqrt((sm[0][0] + sm[0][1]) + (sm[0][2] + sm[0][3])), nb = sqrt((sm[1][0] + sm[1][1]) + (sm[1][2] + sm[1][3]));
+        double ta = 0.0, tb = 0.0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { ta += sm[0][w]; tb += sm[1][w]; }
+        double na = sqrt(ta), nb = sqrt(tb);
         double err = (na + nb) * inv_rc;
         state->err = err;
         state->iters += 1;
@@ -194,7 +202,7 @@ extern "C" int ofri_ls_compute(ofri_ctx *ctx, const float *im1, const float *im2
     PoolBuf planes(ctx), pp(ctx), st(ctx), parts(ctx);
     OFRI_TRY(planes.get(8 * bytes));
     OFRI_TRY(pp.get(4 * bytes));
-    dim3 b(LS_TX, LS_TY), g(ceil_div(cols, LS_TX), ceil_div(rows, LS_TY));
+    dim3 b(LS_TX, LS_TY / LS_RPT), g(ceil_div(cols, LS_TX), ceil_div(rows, LS_TY));
     const int nblocks = g.x * g.y;
     OFRI_TRY(st.get(sizeof(LsState)));
     OFRI_TRY(parts.get((size_t)nblocks * 2 * sizeof(double)));
@@ -221,7 +229,7 @@ extern "C" int ofri_ls_compute(ofri_ctx *ctx, const float *im1, const float *im2
         float *du = (k & 1) ? a0 : b0, *dv = (k & 1) ? a1 : b1;
         k_ls_sweep<<<g, b, 0, ctx->stream>>>(su, sv, du, dv, f, h, rows, cols, state, parts.as<double>());
         OFRI_LAUNCH_CHECK();
-        k_ls_check<<<1, 256, 0, ctx->stream>>>(parts.as<double>(), nblocks, inv_rc, tol, state);
+        k_ls_check<<<1, 1024, 0, ctx->stream>>>(parts.as<double>(), nblocks, inv_rc, tol, state);
         OFRI_LAUNCH_CHECK();
     }
     {

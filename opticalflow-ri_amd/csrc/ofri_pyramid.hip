@@ -54,8 +54,11 @@ static int get_resample_table(ofri_ctx *ctx, int n_in, int n_out, int filter, Re
     return OFRI_OK;
 }
 
-// AXIS = 1: resample along x (rows kept);  AXIS = 0: along y (columns kept)
-template <int AXIS>
+// AXIS = 1: resample along x (rows kept);  AXIS = 0: along y (columns kept).
+// KS > 0: the window never exceeds KS taps; all KS loads are issued up front (index clamped into the
+// window, weight 0 beyond it - adding an exact +0 product leaves the float64 sum unchanged) so the
+// sequential float64 accumulation does not wait on one load per tap.  KS = 0: any window length.
+template <int AXIS, int KS>
 __global__ void k_resample(const float *__restrict__ in, int H_in, int W_in, float *__restrict__ out,
                            int H_out, int W_out, ResampleTable t) {
     int x = blockIdx.x * blockDim.x + threadIdx.x;
@@ -65,15 +68,32 @@ __global__ void k_resample(const float *__restrict__ in, int H_in, int W_in, flo
     int lo = t.bounds[2 * o], cnt = t.bounds[2 * o + 1];
     const double *k = t.w + o;
     const size_t ks = (size_t)t.n_out;
+    const float *base = AXIS == 1 ? in + (size_t)y * W_in + lo : in + (size_t)lo * W_in + x;
+    const size_t step = AXIS == 1 ? 1 : (size_t)W_in;
     double ss = 0.0;
-    if (AXIS == 1) {
-        const float *row = in + (size_t)y * W_in + lo;
-        for (int i = 0; i < cnt; ++i) ss = __dadd_rn(ss, __dmul_rn((double)row[i], k[i * ks]));
+    if (KS > 0) {
+        float v[KS > 0 ? KS : 1];
+        double w[KS > 0 ? KS : 1];
+#pragma unroll
+        for (int i = 0; i < KS; ++i) {
+            int ii = i < cnt ? i : (cnt > 0 ? cnt - 1 : 0);
+            v[i] = base[(size_t)ii * step];
+            w[i] = i < cnt ? k[i * ks] : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < KS; ++i) ss = __dadd_rn(ss, __dmul_rn((double)v[i], w[i]));
     } else {
-        const float *col = in + (size_t)lo * W_in + x;
-        for (int i = 0; i < cnt; ++i) ss = __dadd_rn(ss, __dmul_rn((double)col[(size_t)i * W_in], k[i * ks]));
+        for (int i = 0; i < cnt; ++i) ss = __dadd_rn(ss, __dmul_rn((double)base[(size_t)i * step], k[i * ks]));
     }
     out[(size_t)y * W_out + x] = (float)ss;
+}
+
+template <int AXIS>
+static void resample_launch(ofri_ctx *ctx, dim3 g, dim3 b, const float *in, int H_in, int W_in, float *out, int H_out,
+                            int W_out, const ResampleTable &t) {
+    if (t.ksize <= 5) k_resample<AXIS, 5><<<g, b, 0, ctx->stream>>>(in, H_in, W_in, out, H_out, W_out, t);
+    else if (t.ksize <= 9) k_resample<AXIS, 9><<<g, b, 0, ctx->stream>>>(in, H_in, W_in, out, H_out, W_out, t);
+    else k_resample<AXIS, 0><<<g, b, 0, ctx->stream>>>(in, H_in, W_in, out, H_out, W_out, t);
 }
 
 static int resize_generic(ofri_ctx *ctx, const float *src, int rows_in, int cols_in, float *dst,
@@ -96,7 +116,7 @@ static int resize_generic(ofri_ctx *ctx, const float *src, int rows_in, int cols
         float *o = dst;
         if (need_v) { OFRI_TRY(tmp.get((size_t)rows_in * cols_out * sizeof(float))); o = tmp.as<float>(); }
         dim3 g(ceil_div(cols_out, 64), ceil_div(rows_in, 4));
-        k_resample<1><<<g, b, 0, ctx->stream>>>(cur, rows_in, cols_in, o, rows_in, cols_out, t);
+        resample_launch<1>(ctx, g, b, cur, rows_in, cols_in, o, rows_in, cols_out, t);
         OFRI_LAUNCH_CHECK();
         cur = o;
     }
@@ -104,7 +124,7 @@ static int resize_generic(ofri_ctx *ctx, const float *src, int rows_in, int cols
         ResampleTable t;
         OFRI_TRY(get_resample_table(ctx, rows_in, rows_out, filter, &t));
         dim3 g(ceil_div(cols_out, 64), ceil_div(rows_out, 4));
-        k_resample<0><<<g, b, 0, ctx->stream>>>(cur, rows_in, cols_out, dst, rows_out, cols_out, t);
+        resample_launch<0>(ctx, g, b, cur, rows_in, cols_out, dst, rows_out, cols_out, t);
         OFRI_LAUNCH_CHECK();
     }
     return OFRI_OK;
