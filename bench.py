@@ -34,6 +34,8 @@ def parse():
     ap.add_argument("--fuse", type=int, default=0, help="Jacobi sweeps per launch (0 = automatic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--same-device", action="store_true", help="all ranks compute on GPU 0 (rehearsal on a one-GPU box)")
     ap.add_argument("--with-transfer", action="store_true", help="also report the rate including H2D/D2H copies")
     return ap.parse_args()
 
@@ -65,8 +67,9 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(args.backend)
 
     import _ofri
     from piv_synth import synth_piv
@@ -74,12 +77,14 @@ def main():
     from GenericPyramidalOpticalFlow import pyramidal_flow_device
 
     H = W = args.size
-    if world > 1:
-        stream = torch.cuda.Stream(device=local)
+    dev = 0 if args.same_device else local        # --same-device: rehearse several ranks on a one-GPU box
+    stream = None
+    if world > 1 and args.backend == "nccl":
+        stream = torch.cuda.Stream(device=dev)
         torch.cuda.set_stream(stream)
-        ctx = _ofri.Context(local, stream.cuda_stream)
+        ctx = _ofri.Context(dev, stream.cuda_stream)
     else:
-        ctx = _ofri.Context(local)
+        ctx = _ofri.Context(dev)
     ctx.set_hs_fuse(args.fuse)
 
     # synthetic pair of this rank, resident in HBM as float32 before the timed region
@@ -91,12 +96,20 @@ def main():
     _ofri.check(lib.ofri_u8_to_f32(ctx.handle, u1.ptr, im1.ptr, H * W))
     ctx.sync()
 
+    # Every pair's flow field goes to rank 0 (the only exchange of the job).  The gather of pair i runs
+    # on a side stream while pair i+1 is computed; two send buffers alternate.
     gather = world > 1 and not args.no_gather
+    gather_note = "none"
+    pending = []
     if gather:
-        out_t = [torch.empty((2, H, W), dtype=torch.float32, device="cuda") for _ in range(2)]
-        recv = [torch.empty((2, H, W), dtype=torch.float32, device="cuda") for _ in range(world)] if rank == 0 else None
-        comm_stream = torch.cuda.Stream(device=local)
-        pending = []
+        try:
+            tdev = "cuda" if args.backend == "nccl" else "cpu"
+            out_t = [torch.empty((2, H, W), dtype=torch.float32, device=tdev) for _ in range(2)]
+            recv = [torch.empty((2, H, W), dtype=torch.float32, device=tdev) for _ in range(world)] if rank == 0 else None
+            comm_stream = torch.cuda.Stream(device=dev) if tdev == "cuda" else None
+            gather_note = "%s gather to rank 0 per pair, overlapped with the next pair" % ("rccl" if tdev == "cuda" else args.backend)
+        except Exception as e:                       # keep the compute measurement alive
+            gather, gather_note = False, "disabled: %r" % (e,)
 
     def step(i):
         Ua, Va = pyramidal_flow_device(im0, im1, 3.4, HSOpticalFlowAlgoAdapter([21, 45], args.niter), 2, 1, None)
@@ -104,22 +117,29 @@ def main():
             buf = out_t[i & 1]
             if len(pending) >= 2:
                 pending.pop(0).wait()           # the buffer we are about to overwrite has been sent
-            _ofri.check(lib.ofri_copy(ctx.handle, buf[0].data_ptr(), Ua.ptr, Ua.nbytes))
-            _ofri.check(lib.ofri_copy(ctx.handle, buf[1].data_ptr(), Va.ptr, Va.nbytes))
-            comm_stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(comm_stream):
+            if comm_stream is not None:
+                _ofri.check(lib.ofri_copy(ctx.handle, buf[0].data_ptr(), Ua.ptr, Ua.nbytes))
+                _ofri.check(lib.ofri_copy(ctx.handle, buf[1].data_ptr(), Va.ptr, Va.nbytes))
+                comm_stream.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(comm_stream):
+                    pending.append(dist.gather(buf, recv, dst=0, async_op=True))
+            else:
+                buf[0].copy_(torch.from_numpy(Ua.numpy())); buf[1].copy_(torch.from_numpy(Va.numpy()))
                 pending.append(dist.gather(buf, recv, dst=0, async_op=True))
         return Ua, Va
 
     def fence():
-        if gather:
-            while pending:
-                pending.pop(0).wait()
-            torch.cuda.current_stream().wait_stream(comm_stream)
-        if world > 1:
+        while pending:
+            pending.pop(0).wait()
+        if world > 1 and args.backend == "nccl":
+            if gather:
+                torch.cuda.current_stream().wait_stream(comm_stream)
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
+        elif world > 1:
+            ctx.sync()
+            dist.barrier()
         else:
             ctx.sync()
 
@@ -136,9 +156,8 @@ def main():
     ctx.prof_enable(False)
 
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        from piv_batch import max_over_ranks
+        dt = max_over_ranks(dt, device="cuda" if args.backend == "nccl" else None)
 
     result = None
     if rank == 0:
@@ -160,7 +179,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "HS Fs3.4, 2-level pyramid, %dx%d synthetic Poiseuille pair, alphas [21,45], "
                                    "%d sweeps/level" % (H, W, args.niter),
-                       "pairs_per_step_per_gpu": 1, "flow_gather": "rccl gather to rank 0, overlapped" if gather else "none",
+                       "pairs_per_step_per_gpu": 1, "flow_gather": gather_note,
                        "hs_sweeps_per_launch": sweeps_per_launch},
             "roofline": {"bound": "hbm", "kernel": "hs_jacobi_sweep@%dx%d" % (H, W), "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
