@@ -62,10 +62,23 @@ int ofri_zero(ofri_ctx *ctx, void *dst, size_t bytes);
 int ofri_u8_to_f32(ofri_ctx *ctx, const unsigned char *src, float *dst, size_t n);
 int ofri_u16_to_f32(ofri_ctx *ctx, const unsigned short *src, float *dst, size_t n);
 
+/* The 16-bit -> 8-bit range rule of benchmark_of_methods.py:134-137: if max(frame0) > 255 both frames
+ * become float32(x / 65535 * 255); decided on the GPU, nothing blocks. */
+int ofri_range_rule_16bit(ofri_ctx *ctx, float *frame0, float *frame1, size_t n);
+/* pinned host memory and stream-ordered copies (no reference counterpart: the reference uploads every
+ * operand synchronously per kernel call, Farneback_PyCL.py:225-235); ofri_ctx_wait orders one
+ * context's stream after another's, so a copy context can feed a compute context */
+int ofri_host_alloc(size_t bytes, void **hptr);
+int ofri_host_free(void *hptr);
+int ofri_upload_async(ofri_ctx *ctx, void *dst, const void *src_pinned_host, size_t bytes);
+int ofri_download_async(ofri_ctx *ctx, void *dst_pinned_host, const void *src, size_t bytes);
+int ofri_ctx_wait(ofri_ctx *ctx, ofri_ctx *other);
+
 /* HIP events on the context's stream, for timing kernels from a host language */
 int ofri_event_create(ofri_ctx *ctx, ofri_event **ev);
 int ofri_event_record(ofri_ctx *ctx, ofri_event *ev);
 int ofri_event_elapsed_ms(ofri_event *start, ofri_event *stop, float *ms);          /* syncs on stop */
+int ofri_event_sync(ofri_event *ev);                                                /* host waits */
 int ofri_event_destroy(ofri_event *ev);
 
 /* ---- Gaussian pre-filter -------------------------------------------------------------------- */

@@ -39,9 +39,16 @@ _PROTOS = {
     "ofri_zero": ([_vp, _vp, _sz], _i),
     "ofri_u8_to_f32": ([_vp, _vp, _vp, _sz], _i),
     "ofri_u16_to_f32": ([_vp, _vp, _vp, _sz], _i),
+    "ofri_range_rule_16bit": ([_vp, _vp, _vp, _sz], _i),
+    "ofri_host_alloc": ([_sz, C.POINTER(_vp)], _i),
+    "ofri_host_free": ([_vp], _i),
+    "ofri_upload_async": ([_vp, _vp, _vp, _sz], _i),
+    "ofri_download_async": ([_vp, _vp, _vp, _sz], _i),
+    "ofri_ctx_wait": ([_vp, _vp], _i),
     "ofri_event_create": ([_vp, C.POINTER(_vp)], _i),
     "ofri_event_record": ([_vp, _vp], _i),
     "ofri_event_elapsed_ms": ([_vp, _vp, C.POINTER(_f)], _i),
+    "ofri_event_sync": ([_vp], _i),
     "ofri_event_destroy": ([_vp], _i),
     "ofri_gauss_sep": ([_vp, _vp, _vp, _i, _i, _vp, _i], _i),
     "ofri_gauss_taps": ([_d, _i, _vp], _i),

@@ -204,6 +204,12 @@ extern "C" int ofri_event_elapsed_ms(ofri_event *start, ofri_event *stop, float 
     OFRI_HIP(hipEventElapsedTime(ms, start->ev, stop->ev));
     return OFRI_OK;
 }
+extern "C" int ofri_event_sync(ofri_event *ev) {
+    OFRI_REQUIRE(ev, "ev is null");
+    OFRI_HIP(hipSetDevice(ev->device));
+    OFRI_HIP(hipEventSynchronize(ev->ev));
+    return OFRI_OK;
+}
 extern "C" int ofri_event_destroy(ofri_event *ev) {
     if (!ev) return OFRI_OK;
     (void)hipSetDevice(ev->device);
@@ -237,6 +243,17 @@ extern "C" int ofri_u16_to_f32(ofri_ctx *ctx, const unsigned short *src, float *
     k_to_f32<unsigned short><<<grid_for(n, 256), 256, 0, ctx->stream>>>(src, dst, n);
     OFRI_LAUNCH_CHECK();
     return OFRI_OK;
+}
+
+// (x / 65535 * 255) in float32, applied to both frames only when the first frame's maximum exceeds 255
+// (the 16-bit -> 8-bit range rule of the reference's benchmark script); the decision is taken on the GPU
+__global__ void k_range_rule(float *__restrict__ a, float *__restrict__ b, size_t n, const double *__restrict__ maxa) {
+    if (!((float)maxa[0] > 255.0f)) return;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, st = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += st) {
+        a[i] = __fmul_rn(__fdiv_rn(a[i], 65535.0f), 255.0f);
+        b[i] = __fmul_rn(__fdiv_rn(b[i], 65535.0f), 255.0f);
+    }
 }
 
 __global__ void k_add_inplace(float *__restrict__ acc, const float *__restrict__ x, size_t n) {
@@ -328,6 +345,7 @@ static int ensure_red(ofri_ctx *ctx) {
     return OFRI_OK;
 }
 
+double *ofri_red_slot(ofri_ctx *ctx, int slot);
 // device-side |a-b|_F into slot `slot` (0..63) of the context's result area; no host sync
 int ofri_norm_diff_dev(ofri_ctx *ctx, const float *a, const float *b, size_t n, int slot) {
     OFRI_TRY(ensure_red(ctx));
@@ -371,5 +389,52 @@ extern "C" int ofri_max(ofri_ctx *ctx, const float *a, size_t n, float *out_host
     double d;
     OFRI_TRY(ofri_read_slots(ctx, 0, 1, &d));
     *out_host = (float)d;
+    return OFRI_OK;
+}
+
+int ofri_max_dev(ofri_ctx *ctx, const float *a, size_t n, int slot);
+extern "C" int ofri_range_rule_16bit(ofri_ctx *ctx, float *frame0, float *frame1, size_t n) {
+    OFRI_TRY(ofri_check_ctx(ctx));
+    OFRI_REQUIRE(frame0 && frame1, "null pointer");
+    if (!n) return OFRI_OK;
+    OFRI_TRY(ofri_max_dev(ctx, frame0, n, 4));
+    k_range_rule<<<grid_for(n, 256), 256, 0, ctx->stream>>>(frame0, frame1, n, ofri_red_slot(ctx, 4));
+    OFRI_LAUNCH_CHECK();
+    return OFRI_OK;
+}
+
+// pinned host staging and stream-ordered uploads, for overlapping the next pair's H2D copy with compute
+extern "C" int ofri_host_alloc(size_t bytes, void **hptr) {
+    OFRI_REQUIRE(hptr && bytes > 0, "bad argument");
+    OFRI_HIP(hipHostMalloc(hptr, bytes, hipHostMallocDefault));
+    return OFRI_OK;
+}
+extern "C" int ofri_host_free(void *hptr) {
+    if (hptr) OFRI_HIP(hipHostFree(hptr));
+    return OFRI_OK;
+}
+extern "C" int ofri_upload_async(ofri_ctx *ctx, void *dst, const void *src_pinned_host, size_t bytes) {
+    OFRI_TRY(ofri_check_ctx(ctx));
+    OFRI_REQUIRE(dst && src_pinned_host, "null pointer");
+    if (!bytes) return OFRI_OK;
+    OFRI_HIP(hipMemcpyAsync(dst, src_pinned_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return OFRI_OK;
+}
+extern "C" int ofri_download_async(ofri_ctx *ctx, void *dst_pinned_host, const void *src, size_t bytes) {
+    OFRI_TRY(ofri_check_ctx(ctx));
+    OFRI_REQUIRE(dst_pinned_host && src, "null pointer");
+    if (!bytes) return OFRI_OK;
+    OFRI_HIP(hipMemcpyAsync(dst_pinned_host, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return OFRI_OK;
+}
+// make this context's stream wait for everything enqueued so far on another context's stream
+extern "C" int ofri_ctx_wait(ofri_ctx *ctx, ofri_ctx *other) {
+    OFRI_TRY(ofri_check_ctx(ctx));
+    OFRI_REQUIRE(other && other->device == ctx->device, "contexts must share a device");
+    hipEvent_t ev;
+    OFRI_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    OFRI_HIP(hipEventRecord(ev, other->stream));
+    OFRI_HIP(hipStreamWaitEvent(ctx->stream, ev, 0));
+    OFRI_HIP(hipEventDestroy(ev));
     return OFRI_OK;
 }

@@ -100,7 +100,7 @@ k_fb_window(const float *__restrict__ src, float *__restrict__ dst, float *__res
     const int TW = BL_TX + 2 * ksh, TH = BL_TY + 2 * ksh;
     float *tin = lds;                     // TH x TW
     float *tv = lds + (size_t)TH * TW;    // BL_TY x TW
-    const int bx = blockIdx.x * BL_TX, by = blockIdx.y * BL_TY, tid = threadIdx.y * 64 + threadIdx.x;
+    const int bx = blockIdx.x * BL_TX, by = blockIdx.y * BL_TY;
     const size_t P = (size_t)H * W;
     float res[NP][4];
 #pragma unroll
