@@ -108,8 +108,8 @@ __device__ inline double ls_wave_sum(double v) {
 // One sweep.  A 64x4-thread workgroup owns a 64 x 16 pixel tile (4 rows per thread); the u/v tile with a
 // one-pixel apron is staged in LDS.  Blocks exit at once when the stopping rule has already been met.
 #define LS_TX 64
-#define LS_TY 16
-#define LS_RPT 4
+#define LS_TY 8
+#define LS_RPT 2
 __global__ void __launch_bounds__(256)
 k_ls_sweep(const float *__restrict__ u, const float *__restrict__ v, float *__restrict__ un, float *__restrict__ vn,
            LsFields f, float h, int H, int W, const LsState *__restrict__ state, double *__restrict__ partials) {
