@@ -84,7 +84,7 @@ def test_hs_exact_mode_matches_reference_bits(ctx, alpha, nit, init):
     assert err == pytest.approx(float(h[key + "_err"]), rel=1e-5)
 
 
-@pytest.mark.parametrize("fuse", [0, 1])
+@pytest.mark.parametrize("fuse", [0, 1, 16])
 @pytest.mark.parametrize("alpha,nit,init", CASES)
 def test_hs_fast_mode_within_tolerance(ctx, fuse, alpha, nit, init):
     import HornSchunck as H
@@ -124,7 +124,7 @@ def test_hs_ragged_shapes_vs_oracle(ctx, shape):
     a = rng.uniform(0, 255, shape).astype(np.float32); b = rng.uniform(0, 255, shape).astype(np.float32)
     U0 = rng.standard_normal(shape).astype(np.float32); V0 = rng.standard_normal(shape).astype(np.float32)
     Ur, Vr, er = hs.hs(a, b, 7.5, 13, U0.copy(), V0.copy())
-    for fuse, tol in ((-1, 0.0), (1, 1e-5), (0, 1e-5)):
+    for fuse, tol in ((-1, 0.0), (1, 1e-5), (0, 1e-5), (16, 1e-5)):
         ctx.set_hs_fuse(fuse)
         try:
             U, V, e = H.HS(a, b, 7.5, 13, U0.copy(), V0.copy())
@@ -134,6 +134,27 @@ def test_hs_ragged_shapes_vs_oracle(ctx, shape):
             np.testing.assert_array_equal(U, Ur); np.testing.assert_array_equal(V, Vr)
         else:
             assert flow_rel(U, V, Ur, Vr) <= tol, (fuse, shape)
+
+
+@pytest.mark.parametrize("shape,nit", [((1, 8), 5), ((5, 12), 16), ((40, 200), 33), ((300, 100), 17), ((257, 1000), 48),
+                                       ((700, 96), 100), ((64, 2052), 20)])
+def test_hs_launch_shapes_agree_bitwise(ctx, shape, nit):
+    """One sweep per launch, the tile kernel (8 sweeps per launch) and the row-streaming pipeline
+    (16 per launch) share one arithmetic sequence: their results are the same bits."""
+    from HornSchunck import hs_iterate_device
+    rng = np.random.default_rng(shape[0] * 7 + shape[1] + nit)
+    host = [rng.standard_normal(shape).astype(np.float32) for _ in range(5)]
+    out = {}
+    for fuse in (1, 8, 16):
+        ctx.set_hs_fuse(fuse)
+        try:
+            d = [ctx.upload(x) for x in host]
+            hs_iterate_device(d[0], d[1], d[2], d[3], d[4], 3.0, nit)
+            out[fuse] = (d[0].numpy(), d[1].numpy())
+        finally:
+            ctx.set_hs_fuse(0)
+    for fuse in (8, 16):
+        np.testing.assert_array_equal(out[fuse][0], out[1][0]); np.testing.assert_array_equal(out[fuse][1], out[1][1])
 
 
 def test_hs_zero_iterations_returns_input(ctx):
