@@ -31,6 +31,7 @@ extern "C" {
 #define OFRI_EHIP       -2   /* a HIP runtime call failed; message carries hipGetErrorString */
 #define OFRI_ENOMEM     -3   /* device allocation failed */
 #define OFRI_ENODEVICE  -4   /* no usable GPU */
+#define OFRI_ERANGE     -5   /* a data-dependent index left the array (the reference's IndexError) */
 
 typedef struct ofri_ctx ofri_ctx;
 typedef struct ofri_event ofri_event;
@@ -189,6 +190,13 @@ int ofri_warp_flow(ofri_ctx *ctx, const float *img, const float *U, const float 
  * out2 = im2 at (y + V/2, x + U/2). */
 int ofri_warp_pair(ofri_ctx *ctx, const float *im1, const float *im2, const float *U, const float *V,
                    float *out1, float *out2, int rows, int cols);
+/* the warp of updateNextPyramidalLevel with biLinear=False (src/GenericPyramidalOpticalFlow.py:189-221): pixels of
+ * im move by (floor(V+0.5), floor(U+0.5)) (last writer in row-major order wins, negative destinations count from
+ * the far edge), then out = shifted - (d(shifted*dU)/dx + d(shifted*dV)/dy) with the fractional parts dU, dV
+ * smoothed by ofri_gauss_sep(taps) (the driver passes sigma 1.8, 73 taps).  A destination outside [-n, n) returns OFRI_ERANGE with the reference's
+ * IndexError text in ofri_last_error().  out may equal im (the reference overwrites its argument). */
+int ofri_warp_shift_ofe(ofri_ctx *ctx, const float *im, const float *U, const float *V, float *out,
+                        int rows, int cols, const float *taps_host, int ntaps);
 /* acc += x  (Uaccum += U, src/GenericPyramidalOpticalFlow.py:413-414);  y *= s */
 int ofri_add_inplace(ofri_ctx *ctx, float *acc, const float *x, size_t n);
 int ofri_scale_inplace(ofri_ctx *ctx, float *y, float s, size_t n);

@@ -44,8 +44,24 @@ def warp_flow_device(im, U, V, half_sign):
     return out
 
 
+def shift_warp_device(im, us, vs):
+    """The biLinear=False warp (reference :189-221): integer shift of every pixel, then the optical-flow
+    equation on the Gaussian-smoothed fractional displacements.  Returns a new array (the reference
+    overwrites its argument; callers that rely on that take the result in its place).  Raises IndexError
+    where the reference's fancy-index assignment does (a destination outside [-n, n))."""
+    mask_size = 3
+    sigma, truncate = 0.6 * mask_size, 4.0 / 0.6 * mask_size                 # :210-212
+    taps = prepareGaussianKernel(sigma, 2 * int(truncate * sigma + 0.5) + 1)   # gaussian_filter.py:87-89
+    out = im.ctx.empty(im.shape)
+    _ofri.check(_ofri.lib().ofri_warp_shift_ofe(im.ctx.handle, im.ptr, us.ptr, vs.ptr, out.ptr, im.shape[0], im.shape[1],
+                                                taps.ctypes.data, int(taps.size)))
+    return out
+
+
 def next_level_device(im1, prev_shape, im2, Uacc, Vacc, warping=True, biLinear=True, scale=False):
-    """Level transition (reference updateNextPyramidalLevel, :118-235) on device arrays."""
+    """Level transition (reference updateNextPyramidalLevel, :118-235) on device arrays.  With
+    warping and not biLinear the reference overwrites its first image; here the first returned array is
+    that image and the argument is left alone."""
     ctx = im1.ctx
     H, W = im1.shape
     sx = np.float32(np.float32(W) / np.float32(prev_shape[1])) if scale else np.float32(1.0)
@@ -64,8 +80,8 @@ def next_level_device(im1, prev_shape, im2, Uacc, Vacc, warping=True, biLinear=T
     if not warping:
         return im1, im2, ctx.zeros((H, W)), ctx.zeros((H, W)), us, vs
     if not biLinear:
-        raise NotImplementedError("biLinear=False (optical-flow-equation warp of the reference, "
-                                  "GenericPyramidalOpticalFlow.py:204-221) is not implemented on the GPU path")
+        _say('Warping: Liu-Shen')
+        return shift_warp_device(im1, us, vs), im2, us, vs, ctx.zeros((H, W)), ctx.zeros((H, W))
     _say('Warping: BiLinear')
     w1, w2 = ctx.empty((H, W)), ctx.empty((H, W))
     _ofri.check(_ofri.lib().ofri_warp_pair(ctx.handle, im1.ptr, im2.ptr, us.ptr, vs.ptr, w1.ptr, w2.ptr, H, W))
@@ -84,9 +100,11 @@ def _compute(adapter, im1, im2, U, V):
 
 def pyramidal_flow_device(im1, im2, FILTER, mainOFlowAlgoAdapter, pyramidalLevels=1, kLevels=1, FILTER_OPT=None,
                           optionalOFlowAlgoAdapter=None, warping=True, biLinear=True,
-                          pyramidalIntermediateScaling=True, pyramidalScaling=False):
+                          pyramidalIntermediateScaling=True, pyramidalScaling=False, overwritten=None):
     """genericPyramidalOpticalFlow on DeviceArrays; returns (Uaccum, Vaccum) DeviceArrays without
-    synchronising the stream."""
+    synchronising the stream.  ``overwritten``: optional dict; with warping and not biLinear the reference
+    overwrites the caller's first image at the last level (:207,221,347), and the image it would hold
+    afterwards is stored under 'im1'."""
     ctx = im1.ctx
     lib = _ofri.lib()
     main, opt = mainOFlowAlgoAdapter, optionalOFlowAlgoAdapter
@@ -122,6 +140,10 @@ def pyramidal_flow_device(im1, im2, FILTER, mainOFlowAlgoAdapter, pyramidalLevel
             n1, n2 = im1, im2
         if level > 1:
             w1, w2, Uacc, Vacc, U, V = next_level_device(n1, prev.shape, n2, Uacc, Vacc, warping, biLinear, lscale)
+            if warping and not biLinear:
+                n1 = w1              # the reference's level image now is the warped one (:207,221)
+                if level == pyramidalLevels and overwritten is not None:
+                    overwritten['im1'] = w1
         else:
             w1, w2 = n1, n2
             U, V = ctx.zeros(n1.shape), ctx.zeros(n1.shape)
@@ -178,7 +200,11 @@ def updateNextPyramidalLevel(im1IterNext, im1IterPrev, im2IterNext, Uaccum, Vacc
     ctx = _ofri.context()
     r = next_level_device(ctx.upload(im1IterNext), im1IterPrev.shape, ctx.upload(im2IterNext), ctx.upload(Uaccum),
                           ctx.upload(Vaccum), warping, biLinear, scale)
-    return tuple(a.numpy() for a in r)
+    out = [a.numpy() for a in r]
+    if warping and not biLinear and isinstance(im1IterNext, np.ndarray):
+        im1IterNext[...] = out[0]            # the reference warps its first argument in place and returns it
+        out[0] = im1IterNext
+    return tuple(out)
 
 
 def genericPyramidalOpticalFlow(im1, im2, FILTER, mainOFlowAlgoAdapter, pyramidalLevels=1, kLevels=1,
@@ -187,7 +213,10 @@ def genericPyramidalOpticalFlow(im1, im2, FILTER, mainOFlowAlgoAdapter, pyramida
     """Same signature and return value as the reference (GenericPyramidalOpticalFlow.py:238-416):
     NumPy images in, (Uaccum, Vaccum) float32 NumPy arrays out."""
     ctx = _ofri.context()
+    changed = {}
     Ua, Va = pyramidal_flow_device(ctx.upload(im1), ctx.upload(im2), FILTER, mainOFlowAlgoAdapter, int(pyramidalLevels),
                                    int(kLevels), FILTER_OPT, optionalOFlowAlgoAdapter, warping, biLinear,
-                                   pyramidalIntermediateScaling, pyramidalScaling)
+                                   pyramidalIntermediateScaling, pyramidalScaling, changed)
+    if 'im1' in changed and isinstance(im1, np.ndarray):
+        im1[...] = changed['im1'].numpy()    # as the reference leaves the caller's first image (biLinear=False)
     return Ua.numpy(), Va.numpy()

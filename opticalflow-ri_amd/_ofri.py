@@ -74,6 +74,7 @@ _PROTOS = {
     "ofri_warp_coords": ([_vp, _vp, _vp, _vp, _vp, _i, _i], _i),
     "ofri_warp_flow": ([_vp, _vp, _vp, _vp, _f, _vp, _i, _i], _i),
     "ofri_warp_pair": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i], _i),
+    "ofri_warp_shift_ofe": ([_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i], _i),
     "ofri_add_inplace": ([_vp, _vp, _vp, _sz], _i),
     "ofri_scale_inplace": ([_vp, _vp, _f, _sz], _i),
     "ofri_norm_diff": ([_vp, _vp, _vp, _sz, C.POINTER(_d)], _i),
@@ -112,6 +113,8 @@ def bind(name, args, res=_i):
 def check(rc):
     if rc != 0:
         msg = lib().ofri_last_error()
+        if rc == -5:                                   # OFRI_ERANGE: the reference's IndexError
+            raise IndexError(msg.decode("utf-8", "replace") if msg else "index out of bounds")
         raise OfriError("libofri_hip error %d: %s" % (rc, msg.decode("utf-8", "replace") if msg else "?"))
 
 

@@ -226,6 +226,29 @@ def main():
         2, 1, None, None, True, True, True, True)
     np.savez_compressed(os.path.join(OUT, "driver.npz"), **d)
 
+    # ---- optical-flow-equation warp, biLinear=False (GenericPyramidalOpticalFlow.py:189-221) --------
+    w = {}
+    wi = I0[60:180, 200:350].copy()                                        # 120 x 150
+    yy, xx = np.mgrid[0:120, 0:150].astype(np.float32)
+    # non-positive shifts: destinations wrap at the low edges, never leave the array at the high edges;
+    # the gradients make several sources land on one destination and leave others untouched
+    Uw = (-3.0 + 2.5 * np.sin(xx / 9.0 + yy / 31.0)).astype(np.float32)
+    Vw = (-1.2 + 1.1 * np.cos(yy / 7.0 - xx / 23.0)).astype(np.float32)
+    w["im"], w["U"], w["V"], w["im2"] = wi, Uw, Vw, I1[60:180, 200:350].copy()
+    arg = wi.copy()
+    (r, _o) = _quiet(G.updateNextPyramidalLevel, arg, np.zeros((120, 150), np.float32), w["im2"].copy(), Uw.copy(), Vw.copy(),
+                     None, None, True, False, False)
+    assert r[0] is arg                                                     # warped in place
+    w["out_im1"], w["out_im2"], w["out_Uacc"], w["out_Vacc"] = r[0], r[1], r[2], r[3]
+    # whole driver, two levels, adapter defaults off so that the caller's biLinear=False applies
+    a0, a1 = I0[:256, :256].copy(), I1[:256, :256].copy()
+    (r, _o) = _quiet(G.genericPyramidalOpticalFlow, a0, a1, 3.4, H.HSOpticalFlowAlgoAdapter([21, 45], 30, False), 2, 1,
+                     None, None, True, False, True, False)
+    w["drv_U"], w["drv_V"], w["drv_im1_after"] = r[0], r[1], a0
+    w["drv_im1_changed"] = np.int64(np.count_nonzero(a0 != I0[:256, :256]))
+    print("shift warp driver:", stats(r[0]), stats(r[1]), int(w["drv_im1_changed"]))
+    np.savez_compressed(os.path.join(OUT, "shiftwarp.npz"), **w)
+
     # ---- Farneback host constant tables (pure Python parts only) ----------------------
     f = {}
     try:

@@ -159,11 +159,30 @@ def warp_bilinear(img, cy, cx):
     return out
 
 
+# --------------------------------------------------------------------------- optical-flow-equation warp
+def warp_shift_ofe(im, us, vs):
+    """The biLinear=False branch of updateNextPyramidalLevel (GenericPyramidalOpticalFlow.py:189-221).
+    Overwrites ``im`` (a float32 array) like the reference and returns it.  ``gaussian_filter`` there is
+    the reference's own K-tap filter (gaussian_filter.py:87-90), not SciPy's."""
+    H, W = im.shape
+    xs, ys = np.meshgrid(np.arange(W, dtype=np.int32), np.arange(H, dtype=np.int32))
+    u_sw = np.int32(xs + np.floor(us + 0.5)); v_sw = np.int32(ys + np.floor(vs + 0.5))
+    dU = us - np.floor(us + np.float32(0.5)); dV = vs - np.floor(vs + np.float32(0.5))
+    im[v_sw, u_sw] = im[ys, xs]
+    mask_size = 3
+    dU = gauss.filter_trunc(dU, 0.6 * mask_size, 4.0 / 0.6 * mask_size)
+    dV = gauss.filter_trunc(dV, 0.6 * mask_size, 4.0 / 0.6 * mask_size)
+    tx = (im[0:-1, 1:] * dU[0:-1, 1:] - im[0:-1, 0:-1] * dU[0:-1, 0:-1]) / 1
+    ty = (im[1:, 0:-1] * dV[1:, 0:-1] - im[0:-1, 0:-1] * dV[0:-1, 0:-1]) / 1
+    im[0:-1, 0:-1] = im[0:-1, 0:-1] - (tx + ty) * 1
+    return im
+
+
 # --------------------------------------------------------------------------- level transition
 def next_level(im1, prev_shape, im2, Uacc, Vacc, warping=True, bilinear=True, scale=False,
                upsample=spline_upsample_lib):
-    """updateNextPyramidalLevel (GenericPyramidalOpticalFlow.py:118-235), bilinear-warp and no-warp
-    modes.  Returns (im1, im2, Uacc, Vacc, U, V) for the new level."""
+    """updateNextPyramidalLevel (GenericPyramidalOpticalFlow.py:118-235).  Returns (im1, im2, Uacc, Vacc,
+    U, V) for the new level; with bilinear=False the first image is overwritten, as in the reference."""
     H, W = im1.shape
     if tuple(prev_shape) != (H, W):
         us = upsample(Uacc, (H, W)); vs = upsample(Vacc, (H, W))
@@ -175,7 +194,8 @@ def next_level(im1, prev_shape, im2, Uacc, Vacc, warping=True, bilinear=True, sc
     if not warping:
         return im1, im2, np.zeros((H, W), np.float32), np.zeros((H, W), np.float32), us, vs
     if not bilinear:
-        raise NotImplementedError("optical-flow-equation warp (:204-221) is outside the oracle")
+        warp_shift_ofe(im1, us, vs)
+        return im1, im2, us, vs, np.zeros((H, W), np.float32), np.zeros((H, W), np.float32)
     xs, ys = np.meshgrid(np.arange(W, dtype=np.int32), np.arange(H, dtype=np.int32))
     w1 = warp_bilinear(im1, np.float32(ys - vs / 2.0), np.float32(xs - us / 2.0))
     w2 = warp_bilinear(im2, np.float32(ys + vs / 2.0), np.float32(xs + us / 2.0))

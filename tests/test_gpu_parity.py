@@ -202,6 +202,50 @@ def test_spline_warp_next_level_vs_fixtures(ctx):
     assert rel_l2(r[0], p["odd_im1"]) < 1e-6 and rel_l2(r[1], p["odd_im2"]) < 1e-6
 
 
+def test_shift_warp_biLinear_false_vs_reference(ctx):
+    """The optical-flow-equation warp (reference :189-221): colliding and wrapping destinations, the
+    73-tap smoothing, the in-place update of the caller's array; then the reference's IndexError."""
+    import GenericPyramidalOpticalFlow as G
+    w = load_gold("shiftwarp")
+    arg = w["im"].copy()
+    r = G.updateNextPyramidalLevel(arg, np.zeros((120, 150), np.float32), w["im2"].copy(), w["U"].copy(), w["V"].copy(),
+                                   None, None, True, False, False)
+    assert r[0] is arg
+    np.testing.assert_array_equal(r[0], w["out_im1"]); np.testing.assert_array_equal(r[1], w["out_im2"])
+    np.testing.assert_array_equal(r[2], w["out_Uacc"]); np.testing.assert_array_equal(r[3], w["out_Vacc"])
+    assert not r[4].any() and not r[5].any()
+    # destinations past the far edge: same exception, same text as NumPy gives the reference
+    for U, V in ((np.full((120, 150), 0.6, np.float32), np.zeros((120, 150), np.float32)),
+                 (np.zeros((120, 150), np.float32), np.full((120, 150), 2.5, np.float32)),
+                 (np.full((120, 150), -151.0, np.float32), np.full((120, 150), 7.5, np.float32))):
+        xs, ys = np.meshgrid(np.arange(150, dtype=np.int32), np.arange(120, dtype=np.int32))
+        with pytest.raises(IndexError) as want:
+            w["im"].copy()[np.int32(ys + np.floor(V + 0.5)), np.int32(xs + np.floor(U + 0.5))] = 0
+        with pytest.raises(IndexError) as got:
+            G.updateNextPyramidalLevel(w["im"].copy(), np.zeros((120, 150), np.float32), w["im2"].copy(), U, V,
+                                       None, None, True, False, False)
+        assert str(got.value) == str(want.value)
+
+
+def test_shift_warp_driver_vs_reference(ctx, pair):
+    """Two levels with warping=True, biLinear=False (adapter defaults off).  The integer part of the
+    shift is a step function of the flow, so agreement is asserted on all but a few pixels."""
+    from HornSchunck import HSOpticalFlowAlgoAdapter as A
+    from GenericPyramidalOpticalFlow import genericPyramidalOpticalFlow as flow
+    w = load_gold("shiftwarp")
+    a0, a1 = pair[0][:256, :256].copy(), pair[1][:256, :256].copy()
+    ctx.set_hs_fuse(-1)
+    try:
+        U, V = flow(a0, a1, 3.4, A([21, 45], 30, False), 2, 1, None, None, True, False, True, False)
+    finally:
+        ctx.set_hs_fuse(0)
+    bad = np.count_nonzero(a0 != w["drv_im1_after"])
+    rel = flow_rel(U, V, w["drv_U"], w["drv_V"])
+    print("shift-warp driver: rel L2", rel, "pixels of the overwritten image that differ:", bad)
+    assert rel < 1e-3 and bad < 0.001 * a0.size
+    assert np.count_nonzero(a0 != pair[0][:256, :256]) > 10000        # the caller's image was overwritten
+
+
 # ------------------------------------------------------------------------------ whole driver
 def _driver_case(name, U, V):
     d = load_gold("driver")

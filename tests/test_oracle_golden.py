@@ -194,3 +194,26 @@ def test_lk_oracle_recovers_uniform_shift():
     flat = np.full((20, 20), 3.0, np.float32)
     U, V = lk.lk_dense(flat, flat, z[:20, :20] + 0.25, z[:20, :20], 5, 13)
     assert (U == 0.25).all() and (V == 0).all()                                          # singular windows keep their input
+
+
+# ------------------------------------------------------------------------------ biLinear=False warp
+def test_shift_warp_matches_reference_bits():
+    from oracle import pyramid
+    w = load_gold("shiftwarp")
+    arg = w["im"].copy()
+    r = pyramid.next_level(arg, (120, 150), w["im2"].copy(), w["U"].copy(), w["V"].copy(), True, False, False)
+    assert r[0] is arg                                           # overwritten in place, as the reference does
+    np.testing.assert_array_equal(r[0], w["out_im1"]); np.testing.assert_array_equal(r[1], w["out_im2"])
+    np.testing.assert_array_equal(r[2], w["out_Uacc"]); np.testing.assert_array_equal(r[3], w["out_Vacc"])
+    assert not r[4].any() and not r[5].any()
+    assert np.count_nonzero(w["out_im1"] != w["im"]) > 1000
+
+
+def test_shift_warp_driver_matches_reference_bits():
+    from oracle import pyramid, hs
+    w = load_gold("shiftwarp")
+    pg = load_gold("pair_parabolic01")
+    a0, a1 = pg["im0"].astype(np.float32)[:256, :256].copy(), pg["im1"].astype(np.float32)[:256, :256].copy()
+    U, V = pyramid.pyramidal_flow(a0, a1, 3.4, hs.HSAdapter([21, 45], 30, False), 2, 1, None, None, True, False, True, False)
+    np.testing.assert_array_equal(U, w["drv_U"]); np.testing.assert_array_equal(V, w["drv_V"])
+    np.testing.assert_array_equal(a0, w["drv_im1_after"])       # the caller's first image is overwritten
