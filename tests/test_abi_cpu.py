@@ -94,3 +94,15 @@ def test_farneback_host_tables_match_reference_fixtures():
     np.testing.assert_array_equal(o.matrixGKernel[0], np.float32(f["bitexact_33_4.95"])[16:])
     with pytest.raises(Exception):
         FB.Farneback_PyCL(windowSize=32)
+
+
+def test_methods_report_table_names():
+    """The ten rows of the reference's benchmark (benchmark_of_methods.py:143-148,197-201,251-255)."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import methods_report
+    assert [r[0] for r in methods_report.method_table()] == [
+        "HS_Fs0_0", "HS_Fs3_4", "HS_Fs3_4_PyrLvls2", "LiuSE_HS_Fs3_4_PyrLvls2",
+        "LK_Fs2_0", "LK_Fs2_0_PyrLvls2", "LiuSE_LK_Fs2_0_PyrLvls2",
+        "FB_Fs0_0", "FB_Fs0_0_PyrLvls2", "LiuSE_FB_Fs0_0_PyrLvls2"]
+    assert [r[2:] for r in methods_report.method_table()][:4] == [(0.0, 1, False), (3.4, 1, False), (3.4, 2, False), (3.4, 2, True)]

@@ -73,3 +73,21 @@ def test_ingestion_matches_host_conversion():
     for (x, y), (p, q) in zip(got, pairs):
         np.testing.assert_array_equal(x, p.astype(np.float32)); np.testing.assert_array_equal(y, q.astype(np.float32))
     assert list(PairFeeder(ctx, iter([]))) == []
+
+
+def test_methods_report_runs_all_ten_configurations(tmp_path):
+    """The reference's benchmark report (benchmark_of_methods.py:142-331) on a 160x160 crop of the bundled pair."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import methods_report
+    out = os.path.join(str(tmp_path), "report")
+    res = methods_report.main(["--crop", "160", "--out", out, "--mat", "--plots", "--dpi", "30", "--no-warm"])
+    assert [r[0] for r in res] == [m[0] for m in methods_report.method_table()] and len(res) == 10
+    for name, dt, U, V in res:
+        assert U.shape == (160, 160) and np.isfinite(U).all() and np.isfinite(V).all(), name
+        assert os.path.exists(os.path.join(out, name + ".mat")) and os.path.exists(os.path.join(out, name + ".png"))
+    lines = open(os.path.join(out, "benchmark_summary.txt")).read().splitlines()
+    assert lines[3].split()[:2] == ["Method", "Time"] and sum(1 for l in lines if l.startswith(("HS_", "LK_", "FB_", "LiuSE_"))) == 10
+    assert os.path.exists(os.path.join(out, "execution_time_comparison.png"))
+    by = {r[0]: r for r in res}
+    assert by["HS_Fs3_4_PyrLvls2"][2][40:120, 30:130].mean() < -0.5      # flow of the bundled pair points in -x
