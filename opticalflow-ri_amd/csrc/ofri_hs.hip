@@ -196,13 +196,14 @@ static int hs_iterate_io(ofri_ctx *ctx, const float *Uin, const float *Vin, floa
     const float a2 = alpha * alpha;         // alpha is a float32 in the reference's compiled signature
     const bool exact = ctx->hs_fuse == -1;  // -1: bit-exact restatement of scipy's float64 accumulation
     {
-        // sweeps_per_launch = 16 selects the row-streaming pipeline (opt-in: at 4096^2 it runs 34 us per sweep
-        // against 22 us for the tile kernel, its LDS traffic of 32 B per pixel-sweep being the limit)
+        // sweeps_per_launch = 16 selects the row-streaming pipeline (12 sweeps per launch).  Opt-in: at 4096^2
+        // it runs 20.8 us per sweep against 22 us for the tile kernel, but a partial last launch costs a whole
+        // one, and smaller fields do not fill its row chunks.
         const void *q[7] = {Uin, Vin, Uout, Vout, fx, fy, ft};
         size_t bits = 0;
         for (int i = 0; i < 7; ++i) bits |= (size_t)q[i];
         const bool can = (bits & 15) == 0 && (cols & 3) == 0 && cols >= 8;
-        if (can && ctx->hs_fuse == ofri_hs_stream_sweeps()) {
+        if (can && ctx->hs_fuse == 16) {
             ofri_ctx::ProfRec rec{};
             if (ctx->prof) {
                 OFRI_HIP(hipEventCreate(&rec.a)); OFRI_HIP(hipEventCreate(&rec.b));

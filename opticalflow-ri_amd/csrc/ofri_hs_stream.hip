@@ -1,26 +1,30 @@
-// Horn-Schunck sweeps as a row-streaming pipeline: 16 Jacobi sweeps per launch for large fields.
+// Horn-Schunck sweeps as a row-streaming pipeline: 12 Jacobi sweeps per launch.
 //
-// A workgroup owns a vertical strip 128 pixels wide (96 stored, halo 16 each side) of a chunk of rows and
-// walks down it one row per step.  Sixteen half-wavefronts are the sixteen sweep levels: at a step, level
-// k turns rows r-1, r, r+1 of level k-1 (row r = newest row - 2 - 2k) into row r of sweep k+1, keeping
-// the two older rows in registers and taking the new one, plus the row's fx, fy, ft and 1/den, from small
-// LDS rings; a ninth wavefront streams the next rows from HBM into the rings, eight rows ahead.  One
-// barrier per step.  Each input pixel is read once per 16 sweeps (times the strip overlap 128/96), which
-// is what the tile kernel cannot reach: its halo grows in both directions.
+// A workgroup owns a vertical strip 128 pixels wide (104 stored, halo 12 each side) of a chunk of rows and
+// walks down it one row per step.  Six half-wavefronts are six pipeline stages of two sweeps each: at
+// a step, stage s turns rows r-1, r, r+1 of its input into row r of sweep 2s+1 and, from that row and the
+// two it made in the steps before, row r-1 of sweep 2s+2, which it hands to stage s+1 through a two-slot
+// LDS ring.  The rows a stage works on stay in its registers; a row's fx, fy, ft and 1/den come from an
+// LDS ring once per stage and serve both of its sweeps.  A fourth wavefront streams the next rows from HBM
+// into the rings, six rows ahead.  One barrier per step; three workgroups (48 KB of LDS each) share a compute
+// unit.  Each input pixel is read once per 12 sweeps (times the strip overlap 128/104), which the tile kernel cannot reach:
+// its halo grows in both directions.
 //
-// The planes are copies padded by 16 mirrored pixels ('mirror' border of the reference: a field extended
+// The planes are copies padded by 12 mirrored pixels ('mirror' border of the reference: a field extended
 // by reflection stays the reflection of itself under the symmetric stencil), so the pipeline has no border
 // cases and every 16-byte access is aligned.  Arithmetic is the shared sequence of ofri_hs_math.h, so the
 // result is bit-identical to the other Horn-Schunck kernels.
 #include "ofri_internal.h"
 #include "ofri_hs_math.h"
 
-#define SL_NL 16                         // levels = sweeps per launch = padding
+#define SL_NL 12                         // sweeps per launch = padding
+#define SL_NS (SL_NL / 2)                // pipeline stages
 #define SL_RX 128                        // strip width (32 lanes x 4 pixels)
 #define SL_OX (SL_RX - 2 * SL_NL)        // stored width
-#define SL_PF 8                          // rows the loader keeps in flight
-#define SL_CR 34                         // coefficient ring rows: rows rho-32 .. rho are live
-#define SL_THREADS (SL_NL * 32 + 64)
+#define SL_PF 6                          // rows the loader keeps in flight
+#define SL_LAG (3 * SL_NS)               // the last stage's second sweep runs this many rows behind the loader
+#define SL_CR SL_LAG                     // coefficient ring rows: rows rho-(SL_LAG-1) .. rho are live
+#define SL_THREADS (SL_NS * 32 + 64)
 
 __device__ __forceinline__ float sl_left(float v) {     // lane-1 (wave_shr:1)
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xF, 0xF, false));
@@ -28,6 +32,7 @@ __device__ __forceinline__ float sl_left(float v) {     // lane-1 (wave_shr:1)
 __device__ __forceinline__ float sl_right(float v) {    // lane+1 (wave_shl:1)
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xF, 0xF, false));
 }
+__device__ __forceinline__ int ceil_div_dev(int a, int b) { return (a + b - 1) / b; }
 __device__ __forceinline__ int sl_refl(int i, int n) {
     if (n == 1) return 0;
     int p = 2 * n - 2;
@@ -37,120 +42,142 @@ __device__ __forceinline__ int sl_refl(int i, int n) {
 }
 
 struct SlPlanes { const float *U, *V, *fx, *fy, *ft, *rd; };   // padded planes, pointers at image pixel (0,0)
+struct SlRow { float u[4], v[4]; };                            // a lane's four pixels of one row
+struct SlCoef { float4 fx, fy, ft, rd; };
 
-__device__ __forceinline__ void sl_step(bool loader, int t, int rho0, int H, int P, int x0, int lcol, int lset, int lj,
-                                        const float *pa, const float *pb, const float *pc, float4 &qa, float4 &qb, float4 &qc,
-                                        float4 (&ring)[SL_NL][4][2][32], float4 (&coef)[SL_CR][4][32], int &lslot, int level,
-                                        int l, int &r, int &cslot, float (&w0u)[4], float (&w0v)[4], float (&w1u)[4],
-                                        float (&w1v)[4], int T, int ya, int yb, bool store_lane, float *__restrict__ Uo,
-                                        float *__restrict__ Vo, long long opitch) {
-        if (loader) {
-            const int rho = rho0 + t;
-            ring[0][rho & 3][lset][lj & 31] = qa;
-            coef[lslot][lset][lj & 31] = qb;
-            coef[lslot][2 + lset][lj & 31] = qc;
-            lslot = lslot + 1 == SL_CR ? 0 : lslot + 1;
-            int row = min(rho + SL_PF, H + SL_NL - 1);
-            long long o = (long long)row * P + x0 + lcol;
-            qa = *reinterpret_cast<const float4 *>(pa + o);
-            qb = *reinterpret_cast<const float4 *>(pb + o);
-            qc = *reinterpret_cast<const float4 *>(pc + o);
-        } else {
-            // newest source row r+1, written one step ago
-            const float4 nu4 = ring[level][(r + 1) & 3][0][l], nv4 = ring[level][(r + 1) & 3][1][l];
-            const float nu[4] = {nu4.x, nu4.y, nu4.z, nu4.w}, nv[4] = {nv4.x, nv4.y, nv4.z, nv4.w};
-            const float4 gx4 = coef[cslot][0][l], gy4 = coef[cslot][1][l], gt4 = coef[cslot][2][l], rd4 = coef[cslot][3][l];
-            const float gx[4] = {gx4.x, gx4.y, gx4.z, gx4.w}, gy[4] = {gy4.x, gy4.y, gy4.z, gy4.w};
-            const float gt[4] = {gt4.x, gt4.y, gt4.z, gt4.w}, rd[4] = {rd4.x, rd4.y, rd4.z, rd4.w};
-            cslot = cslot + 1 == SL_CR ? 0 : cslot + 1;
-            float su[6], sv[6], eu[6], ev[6];
+// one sweep of a row: a = row above, c = the row, b = row below; pass = copy the row instead
+__device__ __forceinline__ SlRow sl_sweep(const SlRow &a, const SlRow &c, const SlRow &b, const SlCoef &g, bool pass) {
+    const float gx[4] = {g.fx.x, g.fx.y, g.fx.z, g.fx.w}, gy[4] = {g.fy.x, g.fy.y, g.fy.z, g.fy.w};
+    const float gt[4] = {g.ft.x, g.ft.y, g.ft.z, g.ft.w}, rd[4] = {g.rd.x, g.rd.y, g.rd.z, g.rd.w};
+    float su[6], sv[6], eu[6], ev[6];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                su[k + 1] = __fadd_rn(w0u[k], nu[k]); sv[k + 1] = __fadd_rn(w0v[k], nv[k]);
-                eu[k + 1] = w1u[k]; ev[k + 1] = w1v[k];
-            }
-            su[0] = sl_left(su[4]); su[5] = sl_right(su[1]);
-            sv[0] = sl_left(sv[4]); sv[5] = sl_right(sv[1]);
-            eu[0] = sl_left(eu[4]); eu[5] = sl_right(eu[1]);
-            ev[0] = sl_left(ev[4]); ev[5] = sl_right(ev[1]);
-            float tu[4], tv[4];
+    for (int k = 0; k < 4; ++k) {
+        su[k + 1] = __fadd_rn(a.u[k], b.u[k]); sv[k + 1] = __fadd_rn(a.v[k], b.v[k]);
+        eu[k + 1] = c.u[k]; ev[k + 1] = c.v[k];
+    }
+    su[0] = sl_left(su[4]); su[5] = sl_right(su[1]);
+    sv[0] = sl_left(sv[4]); sv[5] = sl_right(sv[1]);
+    eu[0] = sl_left(eu[4]); eu[5] = sl_right(eu[1]);
+    ev[0] = sl_left(ev[4]); ev[5] = sl_right(ev[1]);
+    SlRow o;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float ua = hs_avg(__fadd_rn(su[k + 1], __fadd_rn(eu[k], eu[k + 2])), __fadd_rn(su[k], su[k + 2]));
-                float va = hs_avg(__fadd_rn(sv[k + 1], __fadd_rn(ev[k], ev[k + 2])), __fadd_rn(sv[k], sv[k + 2]));
-                hs_update(ua, va, gx[k], gy[k], gt[k], rd[k], tu[k], tv[k]);
-                if (level >= T) { tu[k] = w1u[k]; tv[k] = w1v[k]; }     // fewer than 16 sweeps asked: pass through
-            }
-            if (level < SL_NL - 1) {
-                ring[level + 1][r & 3][0][l] = make_float4(tu[0], tu[1], tu[2], tu[3]);
-                ring[level + 1][r & 3][1][l] = make_float4(tv[0], tv[1], tv[2], tv[3]);
-            } else if (store_lane && r >= ya && r < yb) {
-                long long o = (long long)r * opitch + x0 + 4 * l;
-                *reinterpret_cast<float4 *>(Uo + o) = make_float4(tu[0], tu[1], tu[2], tu[3]);
-                *reinterpret_cast<float4 *>(Vo + o) = make_float4(tv[0], tv[1], tv[2], tv[3]);
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { w0u[k] = w1u[k]; w0v[k] = w1v[k]; w1u[k] = nu[k]; w1v[k] = nv[k]; }
-            ++r;
-        }
+    for (int k = 0; k < 4; ++k) {
+        float ua = hs_avg(__fadd_rn(su[k + 1], __fadd_rn(eu[k], eu[k + 2])), __fadd_rn(su[k], su[k + 2]));
+        float va = hs_avg(__fadd_rn(sv[k + 1], __fadd_rn(ev[k], ev[k + 2])), __fadd_rn(sv[k], sv[k + 2]));
+        hs_update(ua, va, gx[k], gy[k], gt[k], rd[k], o.u[k], o.v[k]);
+        if (pass) { o.u[k] = c.u[k]; o.v[k] = c.v[k]; }
+    }
+    return o;
+}
+
+struct SlStage {                 // registers of one pipeline stage (one lane)
+    SlRow in0, in1;              // input rows rA-1, rA
+    SlRow mid0, mid1;            // rows rA-2, rA-1 of the stage's first sweep
+    SlCoef gprev;                // coefficients of row rA-1
+    int rA;                      // row the first sweep produces at this step
+    int cslot;                   // coefficient ring slot of row rA
+};
+
+// one step of a stage: first sweep at row rA, second sweep at row rA-1
+__device__ __forceinline__ void sl_stage_step(SlStage &st, float4 (&ring)[SL_NS][2][2][32], float4 (&coef)[SL_CR][4][32],
+                                              int stage, int l, bool passA, bool passB, int ya, int yb, bool store_lane,
+                                              int x0, float *__restrict__ Uo, float *__restrict__ Vo, long long opitch) {
+    // newest input row rA+1, written one step ago
+    const float4 nu4 = ring[stage][(st.rA + 1) & 1][0][l], nv4 = ring[stage][(st.rA + 1) & 1][1][l];
+    SlCoef g;
+    g.fx = coef[st.cslot][0][l]; g.fy = coef[st.cslot][1][l]; g.ft = coef[st.cslot][2][l]; g.rd = coef[st.cslot][3][l];
+    st.cslot = st.cslot + 1 == SL_CR ? 0 : st.cslot + 1;
+    SlRow nw;
+    nw.u[0] = nu4.x; nw.u[1] = nu4.y; nw.u[2] = nu4.z; nw.u[3] = nu4.w;
+    nw.v[0] = nv4.x; nw.v[1] = nv4.y; nw.v[2] = nv4.z; nw.v[3] = nv4.w;
+    const SlRow mid2 = sl_sweep(st.in0, st.in1, nw, g, passA);                  // row rA of the first sweep
+    const SlRow out = sl_sweep(st.mid0, st.mid1, mid2, st.gprev, passB);        // row rA-1 of the second sweep
+    const int rB = st.rA - 1;
+    if (stage < SL_NS - 1) {
+        ring[stage + 1][rB & 1][0][l] = make_float4(out.u[0], out.u[1], out.u[2], out.u[3]);
+        ring[stage + 1][rB & 1][1][l] = make_float4(out.v[0], out.v[1], out.v[2], out.v[3]);
+    } else if (store_lane && rB >= ya && rB < yb) {
+        const long long o = (long long)rB * opitch + x0 + 4 * l;
+        *reinterpret_cast<float4 *>(Uo + o) = make_float4(out.u[0], out.u[1], out.u[2], out.u[3]);
+        *reinterpret_cast<float4 *>(Vo + o) = make_float4(out.v[0], out.v[1], out.v[2], out.v[3]);
+    }
+    st.in0 = st.in1; st.in1 = nw;
+    st.mid0 = st.mid1; st.mid1 = mid2;
+    st.gprev = g;
+    ++st.rA;
 }
 
 __global__ void __launch_bounds__(SL_THREADS)
 k_hs_stream(SlPlanes in, float *__restrict__ Uo, float *__restrict__ Vo, long long opitch, int P, int H, int W, int T,
             int tiles_x, int chunk_rows) {
-    __shared__ float4 ring[SL_NL][4][2][32];      // ring[0]: input rows; ring[k+1]: rows of sweep k+1.  [slot][U|V][lane]
+    __shared__ float4 ring[SL_NS][2][2][32];      // ring[s]: input rows of stage s.  [row & 1][U|V][lane]
     __shared__ float4 coef[SL_CR][4][32];         // [row slot][fx|fy|ft|1/den][lane]
     const int tid = threadIdx.x;
     const int strip = blockIdx.x % tiles_x, chunk = blockIdx.x / tiles_x;
     const int ya = chunk * chunk_rows, yb = min(H, ya + chunk_rows);
     const int x0 = strip * SL_OX - SL_NL;          // image x of strip column 0
     const int rho0 = ya - SL_NL;                   // first input row of the chunk
-    const int NS = (yb - ya) + 3 * SL_NL;          // steps until the last level has produced row yb-1
-    const bool loader = tid >= SL_NL * 32;
+    // steps until the last sweep has produced row yb-1, rounded up to whole rounds of the prefetch registers: the
+    // loader's loop then has no branch inside a round, and the compiler can leave the younger loads in flight
+    // (with a branch per step it waits for all of them).  The extra steps store nothing.
+    const int NS = ceil_div_dev((yb - ya) + SL_NL + SL_LAG, SL_PF) * SL_PF;
 
-    // ---- loader state -----------------------------------------------------------------------------
-    const int lj = tid & 63, lcol = 4 * (lj & 31), lset = (lj >> 5) & 1;
-    const float *pa = lset ? in.V : in.U, *pb = lset ? in.fy : in.fx, *pc = lset ? in.rd : in.ft;
-    // rows in flight: named registers (an array here ends up in scratch memory, which serialises the prefetch)
-#define SL_Q(U_) float4 qa##U_, qb##U_, qc##U_;
-    SL_Q(0) SL_Q(1) SL_Q(2) SL_Q(3) SL_Q(4) SL_Q(5) SL_Q(6) SL_Q(7)
+    // The loader and the stages run separate loops (their registers then overlap instead of adding up);
+    // both execute one barrier per step, NS in all.
+    if (tid >= SL_NS * 32) {
+        // ---- loader wavefront: lanes 0-31 carry U, fx, ft; lanes 32-63 carry V, fy, 1/den ------------------
+        const int lj = tid & 31, lcol = 4 * lj, lset = (tid >> 5) & 1;
+        const float *pa = lset ? in.V : in.U, *pb = lset ? in.fy : in.fx, *pc = lset ? in.rd : in.ft;
+        int lslot = (rho0 + 64 * SL_CR) % SL_CR;               // slot of the row written next
+        // rows in flight: named registers (an array here ends up in scratch memory, which serialises the prefetch)
+#define SL_LOAD(U_, ROW_)                                                          \
+    {                                                                              \
+        const int row = min((ROW_), H + SL_NL - 1);                                \
+        const long long o = (long long)row * P + x0 + lcol;                        \
+        qa##U_ = *reinterpret_cast<const float4 *>(pa + o);                        \
+        qb##U_ = *reinterpret_cast<const float4 *>(pb + o);                        \
+        qc##U_ = *reinterpret_cast<const float4 *>(pc + o);                        \
+    }
+        // the compiler must keep the first fill in program order (oldest load = first row consumed), or it has
+        // to wait for every load in flight at the top of each round
+#define SL_Q(U_) float4 qa##U_, qb##U_, qc##U_; SL_LOAD(U_, rho0 + (U_)) asm volatile("" ::: "memory");
+        SL_Q(0) SL_Q(1) SL_Q(2) SL_Q(3) SL_Q(4) SL_Q(5)
 #undef SL_Q
-    static_assert(SL_PF == 8, "the prefetch registers are spelled out for eight rows");
-    // ---- level state ------------------------------------------------------------------------------
-    const int level = tid >> 5, l = tid & 31;
-    float w0u[4] = {0, 0, 0, 0}, w0v[4] = {0, 0, 0, 0}, w1u[4] = {0, 0, 0, 0}, w1v[4] = {0, 0, 0, 0};
-    int r = rho0 - 2 - 2 * level;                              // row this level produces at step 0
-    int cslot = (r + 64 * SL_CR) % SL_CR;                      // its coefficient ring slot
-    int lslot = (rho0 + 64 * SL_CR) % SL_CR;                   // loader: slot of row rho
-    const bool store_lane = l >= SL_NL / 4 && l < 32 - SL_NL / 4 && (x0 + 4 * l) < W;
-
-    if (loader) {
-#define SL_FILL(U_)                                                               \
-    {                                                                             \
-        const int row = min(rho0 + (U_), H + SL_NL - 1);                          \
-        const long long o = (long long)row * P + x0 + lcol;                       \
-        qa##U_ = *reinterpret_cast<const float4 *>(pa + o);                       \
-        qb##U_ = *reinterpret_cast<const float4 *>(pb + o);                       \
-        qc##U_ = *reinterpret_cast<const float4 *>(pc + o);                       \
+        static_assert(SL_PF == 6, "the prefetch registers are spelled out for six rows");
+#define SL_STEP(U_)                                                                \
+    {                                                                              \
+        const int rho = rho0 + t0 + (U_);                                          \
+        ring[0][rho & 1][lset][lj] = qa##U_;                                       \
+        coef[lslot][lset][lj] = qb##U_;                                            \
+        coef[lslot][2 + lset][lj] = qc##U_;                                        \
+        lslot = lslot + 1 == SL_CR ? 0 : lslot + 1;                                \
+        SL_LOAD(U_, rho + SL_PF)                                                   \
+        __syncthreads();                                                           \
     }
-        SL_FILL(0) SL_FILL(1) SL_FILL(2) SL_FILL(3) SL_FILL(4) SL_FILL(5) SL_FILL(6) SL_FILL(7)
-#undef SL_FILL
-    }
-
-    // one pipeline step; U_ names the prefetch registers of the row this step consumes
-#define SL_STEP(U_)                                                                                       \
-    {                                                                                                     \
-        const int t = t0 + (U_);                                                                           \
-        if (t < NS) {                                                                                     \
-            sl_step(loader, t, rho0, H, P, x0, lcol, lset, lj, pa, pb, pc, qa##U_, qb##U_, qc##U_, ring, coef, lslot, level, l, r, cslot,  \
-                       w0u, w0v, w1u, w1v, T, ya, yb, store_lane, Uo, Vo, opitch);                       \
-            __syncthreads();                                                                              \
-        }                                                                                                 \
-    }
-    for (int t0 = 0; t0 < NS; t0 += SL_PF) {
-        SL_STEP(0) SL_STEP(1) SL_STEP(2) SL_STEP(3) SL_STEP(4) SL_STEP(5) SL_STEP(6) SL_STEP(7)
-    }
+        for (int t0 = 0; t0 < NS; t0 += SL_PF) {
+            SL_STEP(0) SL_STEP(1) SL_STEP(2) SL_STEP(3) SL_STEP(4) SL_STEP(5)
+        }
 #undef SL_STEP
+#undef SL_LOAD
+    } else {
+        // ---- stage half-wavefronts ---------------------------------------------------------------------
+        const int stage = tid >> 5, l = tid & 31;
+        SlStage st;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            st.in0.u[k] = st.in0.v[k] = st.in1.u[k] = st.in1.v[k] = 0.f;
+            st.mid0.u[k] = st.mid0.v[k] = st.mid1.u[k] = st.mid1.v[k] = 0.f;
+        }
+        st.gprev.fx = st.gprev.fy = st.gprev.ft = st.gprev.rd = make_float4(0.f, 0.f, 0.f, 0.f);
+        st.rA = rho0 - 2 - 3 * stage;
+        st.cslot = (st.rA + 64 * SL_CR) % SL_CR;
+        const bool passA = 2 * stage >= T, passB = 2 * stage + 1 >= T;    // fewer than 16 sweeps asked: copy rows through
+        const bool store_lane = l >= SL_NL / 4 && l < 32 - SL_NL / 4 && (x0 + 4 * l) < W;
+        // six steps per round (NS is a multiple): the row registers rotate by renaming instead of moves
+#define SL_STEP() sl_stage_step(st, ring, coef, stage, l, passA, passB, ya, yb, store_lane, x0, Uo, Vo, opitch); __syncthreads();
+        for (int t = 0; t < NS; t += SL_PF) { SL_STEP() SL_STEP() SL_STEP() SL_STEP() SL_STEP() SL_STEP() }
+#undef SL_STEP
+    }
 }
 
 // ---- padded copies ------------------------------------------------------------------------------------
@@ -212,11 +239,11 @@ int ofri_hs_stream_run(ofri_ctx *ctx, const float *Uin, const float *Vin, float 
         k_sl_pad<<<g, b, 0, ctx->stream>>>(fx, fy, prd, P, H, W, 1, a2);
         OFRI_LAUNCH_CHECK();
     }
-    // one workgroup per CU (LDS bound): as many row chunks as fill the chip once
+    // three workgroups per CU (48 KB of LDS each): as many row chunks as fill the chip once
     hipDeviceProp_t prop;
     OFRI_HIP(hipGetDeviceProperties(&prop, ctx->device));
     int ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    int nchunks = ncu / tiles_x;
+    int nchunks = 3 * ncu / tiles_x;
     if (nchunks < 1) nchunks = 1;
     int chunk_rows = ceil_div(H, nchunks);
     nchunks = ceil_div(H, chunk_rows);
