@@ -147,7 +147,7 @@ def pyramidal_flow_device(im1, im2, FILTER, mainOFlowAlgoAdapter, pyramidalLevel
         else:
             w1, w2 = n1, n2
             U, V = ctx.zeros(n1.shape), ctx.zeros(n1.shape)
-            Uacc, Vacc = ctx.zeros(n1.shape), ctx.zeros(n1.shape)
+            Uacc = Vacc = None                   # zero so far: the first accumulation adopts U, V instead of adding
         if taps is not None:
             work1, work2 = filter_device(w1, taps), filter_device(w2, taps)
         else:
@@ -174,8 +174,11 @@ def pyramidal_flow_device(im1, im2, FILTER, mainOFlowAlgoAdapter, pyramidalLevel
             if opt is not None:
                 U, V, erro = _compute(opt, o1, o2, U, V)
                 _say(opt.getAlgoName() + ' estimated error for image registration: ' + str(erro))
-            _ofri.check(lib.ofri_add_inplace(ctx.handle, Uacc.ptr, U.ptr, Uacc.size))
-            _ofri.check(lib.ofri_add_inplace(ctx.handle, Vacc.ptr, V.ptr, Vacc.size))
+            if Uacc is None:
+                Uacc, Vacc = U, V                # 0 + U compares equal to U (only a -0 would turn into +0)
+            else:
+                _ofri.check(lib.ofri_add_inplace(ctx.handle, Uacc.ptr, U.ptr, Uacc.size))
+                _ofri.check(lib.ofri_add_inplace(ctx.handle, Vacc.ptr, V.ptr, Vacc.size))
         scale *= 2
     return Uacc, Vacc
 

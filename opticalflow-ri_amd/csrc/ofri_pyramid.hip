@@ -88,10 +88,48 @@ __global__ void k_resample(const float *__restrict__ in, int H_in, int W_in, flo
     out[(size_t)y * W_out + x] = (float)ss;
 }
 
+// Resampling along x with the window's weights held in registers and reused over RS_ROWS rows: the
+// weights depend on the output column only, and loading them per output costs more than the samples.
+#define RS_ROWS 8
+template <int KS>
+__global__ void k_resample_x_rows(const float *__restrict__ in, int H, int W_in, float *__restrict__ out, int W_out,
+                                  ResampleTable t) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y0 = (blockIdx.y * blockDim.y + threadIdx.y) * RS_ROWS;
+    if (x >= W_out || y0 >= H) return;
+    const int lo = t.bounds[2 * x], cnt = t.bounds[2 * x + 1];
+    const double *k = t.w + x;
+    const size_t ks = (size_t)t.n_out;
+    double w[KS];
+    int off[KS];
+#pragma unroll
+    for (int i = 0; i < KS; ++i) {
+        off[i] = lo + (i < cnt ? i : (cnt > 0 ? cnt - 1 : 0));
+        w[i] = i < cnt ? k[i * ks] : 0.0;
+    }
+#pragma unroll 2
+    for (int r = 0; r < RS_ROWS; ++r) {
+        const int y = y0 + r;
+        if (y >= H) break;
+        const float *row = in + (size_t)y * W_in;
+        float v[KS];
+#pragma unroll
+        for (int i = 0; i < KS; ++i) v[i] = row[off[i]];
+        double ss = 0.0;
+#pragma unroll
+        for (int i = 0; i < KS; ++i) ss = __dadd_rn(ss, __dmul_rn((double)v[i], w[i]));
+        out[(size_t)y * W_out + x] = (float)ss;
+    }
+}
+
 template <int AXIS>
 static void resample_launch(ofri_ctx *ctx, dim3 g, dim3 b, const float *in, int H_in, int W_in, float *out, int H_out,
                             int W_out, const ResampleTable &t) {
-    if (t.ksize <= 5) k_resample<AXIS, 5><<<g, b, 0, ctx->stream>>>(in, H_in, W_in, out, H_out, W_out, t);
+    if (AXIS == 1 && t.ksize <= 9) {
+        dim3 gr(g.x, ceil_div(H_out, (int)b.y * RS_ROWS));
+        if (t.ksize <= 5) k_resample_x_rows<5><<<gr, b, 0, ctx->stream>>>(in, H_out, W_in, out, W_out, t);
+        else k_resample_x_rows<9><<<gr, b, 0, ctx->stream>>>(in, H_out, W_in, out, W_out, t);
+    } else if (t.ksize <= 5) k_resample<AXIS, 5><<<g, b, 0, ctx->stream>>>(in, H_in, W_in, out, H_out, W_out, t);
     else if (t.ksize <= 9) k_resample<AXIS, 9><<<g, b, 0, ctx->stream>>>(in, H_in, W_in, out, H_out, W_out, t);
     else k_resample<AXIS, 0><<<g, b, 0, ctx->stream>>>(in, H_in, W_in, out, H_out, W_out, t);
 }
