@@ -68,7 +68,7 @@ __device__ __forceinline__ float avg9(float a00, float a01, float a02, float a10
         t = __dadd_rn(t, __dmul_rn((double)a22, W12));
         return (float)t;
     } else {
-        return hs_avg(__fadd_rn(__fadd_rn(a01, a21), __fadd_rn(a10, a12)), __fadd_rn(__fadd_rn(a00, a20), __fadd_rn(a02, a22)));
+        return hs_avg(__fadd_rn(a01, a21), hs_q(a10, __fadd_rn(a00, a20)), hs_q(a12, __fadd_rn(a02, a22)));
     }
 }
 

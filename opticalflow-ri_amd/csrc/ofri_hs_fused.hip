@@ -19,11 +19,12 @@
 #define FT_S 8                       // rows per thread
 #define FT_BANDS (FT_RY / FT_S)      // 8 bands of 32 lanes
 
+// lane shifts with bound_ctrl: the wavefront's first / last lane reads 0 (a halo pixel, never stored)
 __device__ __forceinline__ float lane_left(float v) {    // value held by lane-1 (wave_shr:1)
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xF, 0xF, false));
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xF, 0xF, true));
 }
 __device__ __forceinline__ float lane_right(float v) {   // value held by lane+1 (wave_shl:1)
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xF, 0xF, false));
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xF, 0xF, true));
 }
 // reflect-101 for any overshoot
 __device__ __forceinline__ int refl101_any(int i, int n) {
@@ -32,6 +33,56 @@ __device__ __forceinline__ int refl101_any(int i, int n) {
     i %= p;
     if (i < 0) i += p;
     return i < n ? i : p - i;
+}
+
+// One sweep of the workgroup's region, in place on the lane's strip; reads the band edge rows of buffer buf,
+// writes the new ones to buffer buf ^ 1.
+__device__ __forceinline__ void ft_sweep(float4 (&edge)[2][FT_BANDS + 2][2][2][32], float4 (&ftile)[FT_RY][32], int buf,
+                                         int band, int l32, float (&cu)[FT_S][4], float (&cv)[FT_S][4],
+                                         const float (&gx)[FT_S][4], const float (&gy)[FT_S][4], const float (&rd)[FT_S][4]) {
+        float4 upU = edge[buf][band][1][0][l32], upV = edge[buf][band][1][1][l32];          // bottom row of the band above
+        float4 dnU = edge[buf][band + 2][0][0][l32], dnV = edge[buf][band + 2][0][1][l32];  // top row of the band below
+        float pu[4] = {upU.x, upU.y, upU.z, upU.w}, pv[4] = {upV.x, upV.y, upV.z, upV.w};
+#pragma unroll
+        for (int r = 0; r < FT_S; ++r) {
+            float nu[4], nv[4];
+            if (r < FT_S - 1) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { nu[k] = cu[r + 1][k]; nv[k] = cv[r + 1][k]; }
+            } else {
+                nu[0] = dnU.x; nu[1] = dnU.y; nu[2] = dnU.z; nu[3] = dnU.w;
+                nv[0] = dnV.x; nv[1] = dnV.y; nv[2] = dnV.z; nv[3] = dnV.w;
+            }
+            // vertical pair sums s and q = 2*centre + s for the lane's columns; q of the columns next to them
+            // comes from the adjacent lanes
+            float su[4], sv[4], qu[6], qv[6];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                su[k] = __fadd_rn(pu[k], nu[k]); sv[k] = __fadd_rn(pv[k], nv[k]);
+                qu[k + 1] = hs_q(cu[r][k], su[k]); qv[k + 1] = hs_q(cv[r][k], sv[k]);
+            }
+            qu[0] = lane_left(qu[4]); qu[5] = lane_right(qu[1]);
+            qv[0] = lane_left(qv[4]); qv[5] = lane_right(qv[1]);
+            float tu[4], tv[4];
+            const float4 g4 = ftile[band * FT_S + r][l32];
+            const float gt[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                // the neighbour lane's value goes first (a + b == b + a exactly): as first operand the lane shift
+                // folds into the add
+                const int p = k == 3 ? k + 2 : k, q = k == 3 ? k : k + 2;
+                float ua = hs_avg(su[k], qu[p], qu[q]);
+                float va = hs_avg(sv[k], qv[p], qv[q]);
+                hs_update(ua, va, gx[r][k], gy[r][k], gt[k], rd[r][k], tu[k], tv[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { pu[k] = cu[r][k]; pv[k] = cv[r][k]; cu[r][k] = tu[k]; cv[r][k] = tv[k]; }
+        }
+        edge[buf ^ 1][band + 1][0][0][l32] = make_float4(cu[0][0], cu[0][1], cu[0][2], cu[0][3]);
+        edge[buf ^ 1][band + 1][0][1][l32] = make_float4(cv[0][0], cv[0][1], cv[0][2], cv[0][3]);
+        edge[buf ^ 1][band + 1][1][0][l32] = make_float4(cu[FT_S - 1][0], cu[FT_S - 1][1], cu[FT_S - 1][2], cu[FT_S - 1][3]);
+        edge[buf ^ 1][band + 1][1][1][l32] = make_float4(cv[FT_S - 1][0], cv[FT_S - 1][1], cv[FT_S - 1][2], cv[FT_S - 1][3]);
+        __syncthreads();
 }
 
 __global__ void __launch_bounds__(256, 2)
@@ -94,50 +145,14 @@ k_hs_fused(const float *__restrict__ U, const float *__restrict__ V, const float
     edge[0][band + 1][1][1][l32] = make_float4(cv[FT_S - 1][0], cv[FT_S - 1][1], cv[FT_S - 1][2], cv[FT_S - 1][3]);
     __syncthreads();
 
-    for (int s = 0; s < T; ++s) {
-        const int buf = s & 1;
-        float4 upU = edge[buf][band][1][0][l32], upV = edge[buf][band][1][1][l32];          // bottom row of the band above
-        float4 dnU = edge[buf][band + 2][0][0][l32], dnV = edge[buf][band + 2][0][1][l32];  // top row of the band below
-        float pu[4] = {upU.x, upU.y, upU.z, upU.w}, pv[4] = {upV.x, upV.y, upV.z, upV.w};
-#pragma unroll
-        for (int r = 0; r < FT_S; ++r) {
-            float nu[4], nv[4];
-            if (r < FT_S - 1) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { nu[k] = cu[r + 1][k]; nv[k] = cv[r + 1][k]; }
-            } else {
-                nu[0] = dnU.x; nu[1] = dnU.y; nu[2] = dnU.z; nu[3] = dnU.w;
-                nv[0] = dnV.x; nv[1] = dnV.y; nv[2] = dnV.z; nv[3] = dnV.w;
-            }
-            // vertical pair sums and centre values for columns x0-1 .. x0+4
-            float su[6], sv[6], eu[6], ev[6];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                su[k + 1] = __fadd_rn(pu[k], nu[k]); sv[k + 1] = __fadd_rn(pv[k], nv[k]);
-                eu[k + 1] = cu[r][k]; ev[k + 1] = cv[r][k];
-            }
-            su[0] = lane_left(su[4]); su[5] = lane_right(su[1]);
-            sv[0] = lane_left(sv[4]); sv[5] = lane_right(sv[1]);
-            eu[0] = lane_left(eu[4]); eu[5] = lane_right(eu[1]);
-            ev[0] = lane_left(ev[4]); ev[5] = lane_right(ev[1]);
-            float tu[4], tv[4];
-            const float4 g4 = ftile[band * FT_S + r][l32];
-            const float gt[4] = {g4.x, g4.y, g4.z, g4.w};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float ua = hs_avg(__fadd_rn(su[k + 1], __fadd_rn(eu[k], eu[k + 2])), __fadd_rn(su[k], su[k + 2]));
-                float va = hs_avg(__fadd_rn(sv[k + 1], __fadd_rn(ev[k], ev[k + 2])), __fadd_rn(sv[k], sv[k + 2]));
-                hs_update(ua, va, gx[r][k], gy[r][k], gt[k], rd[r][k], tu[k], tv[k]);
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { pu[k] = cu[r][k]; pv[k] = cv[r][k]; cu[r][k] = tu[k]; cv[r][k] = tv[k]; }
-        }
-        edge[buf ^ 1][band + 1][0][0][l32] = make_float4(cu[0][0], cu[0][1], cu[0][2], cu[0][3]);
-        edge[buf ^ 1][band + 1][0][1][l32] = make_float4(cv[0][0], cv[0][1], cv[0][2], cv[0][3]);
-        edge[buf ^ 1][band + 1][1][0][l32] = make_float4(cu[FT_S - 1][0], cu[FT_S - 1][1], cu[FT_S - 1][2], cu[FT_S - 1][3]);
-        edge[buf ^ 1][band + 1][1][1][l32] = make_float4(cv[FT_S - 1][0], cv[FT_S - 1][1], cv[FT_S - 1][2], cv[FT_S - 1][3]);
-        __syncthreads();
+    // two sweeps per round, so that the buffer index is a constant and the strip's registers line up again at
+    // the loop's back edge without copies
+    int s = 0;
+    for (; s + 1 < T; s += 2) {
+        ft_sweep(edge, ftile, 0, band, l32, cu, cv, gx, gy, rd);
+        ft_sweep(edge, ftile, 1, band, l32, cu, cv, gx, gy, rd);
     }
+    if (s < T) ft_sweep(edge, ftile, 0, band, l32, cu, cv, gx, gy, rd);
 
     // store the inner tile: bands 1..FT_BANDS-2, strips 2..29, clipped to the image
     if (band >= FT_HALO / FT_S && band < FT_BANDS - FT_HALO / FT_S && l32 >= FT_HALO / 4 && l32 < 32 - FT_HALO / 4 && xin) {

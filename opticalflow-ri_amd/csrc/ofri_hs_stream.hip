@@ -27,10 +27,10 @@
 #define SL_THREADS (SL_NS * 32 + 64)
 
 __device__ __forceinline__ float sl_left(float v) {     // lane-1 (wave_shr:1)
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xF, 0xF, false));
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xF, 0xF, true));
 }
 __device__ __forceinline__ float sl_right(float v) {    // lane+1 (wave_shl:1)
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xF, 0xF, false));
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xF, 0xF, true));
 }
 __device__ __forceinline__ int ceil_div_dev(int a, int b) { return (a + b - 1) / b; }
 __device__ __forceinline__ int sl_refl(int i, int n) {
@@ -49,21 +49,21 @@ struct SlCoef { float4 fx, fy, ft, rd; };
 __device__ __forceinline__ SlRow sl_sweep(const SlRow &a, const SlRow &c, const SlRow &b, const SlCoef &g, bool pass) {
     const float gx[4] = {g.fx.x, g.fx.y, g.fx.z, g.fx.w}, gy[4] = {g.fy.x, g.fy.y, g.fy.z, g.fy.w};
     const float gt[4] = {g.ft.x, g.ft.y, g.ft.z, g.ft.w}, rd[4] = {g.rd.x, g.rd.y, g.rd.z, g.rd.w};
-    float su[6], sv[6], eu[6], ev[6];
+    float su[4], sv[4], qu[6], qv[6];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        su[k + 1] = __fadd_rn(a.u[k], b.u[k]); sv[k + 1] = __fadd_rn(a.v[k], b.v[k]);
-        eu[k + 1] = c.u[k]; ev[k + 1] = c.v[k];
+        su[k] = __fadd_rn(a.u[k], b.u[k]); sv[k] = __fadd_rn(a.v[k], b.v[k]);
+        qu[k + 1] = hs_q(c.u[k], su[k]); qv[k + 1] = hs_q(c.v[k], sv[k]);
     }
-    su[0] = sl_left(su[4]); su[5] = sl_right(su[1]);
-    sv[0] = sl_left(sv[4]); sv[5] = sl_right(sv[1]);
-    eu[0] = sl_left(eu[4]); eu[5] = sl_right(eu[1]);
-    ev[0] = sl_left(ev[4]); ev[5] = sl_right(ev[1]);
+    qu[0] = sl_left(qu[4]); qu[5] = sl_right(qu[1]);
+    qv[0] = sl_left(qv[4]); qv[5] = sl_right(qv[1]);
     SlRow o;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        float ua = hs_avg(__fadd_rn(su[k + 1], __fadd_rn(eu[k], eu[k + 2])), __fadd_rn(su[k], su[k + 2]));
-        float va = hs_avg(__fadd_rn(sv[k + 1], __fadd_rn(ev[k], ev[k + 2])), __fadd_rn(sv[k], sv[k + 2]));
+        // the neighbour lane's value goes first (a + b == b + a exactly): as first operand the lane shift folds into the add
+        const int p = k == 3 ? k + 2 : k, q = k == 3 ? k : k + 2;
+        float ua = hs_avg(su[k], qu[p], qu[q]);
+        float va = hs_avg(sv[k], qv[p], qv[q]);
         hs_update(ua, va, gx[k], gy[k], gt[k], rd[k], o.u[k], o.v[k]);
         if (pass) { o.u[k] = c.u[k]; o.v[k] = c.v[k]; }
     }
@@ -240,9 +240,7 @@ int ofri_hs_stream_run(ofri_ctx *ctx, const float *Uin, const float *Vin, float 
         OFRI_LAUNCH_CHECK();
     }
     // three workgroups per CU (48 KB of LDS each): as many row chunks as fill the chip once
-    hipDeviceProp_t prop;
-    OFRI_HIP(hipGetDeviceProperties(&prop, ctx->device));
-    int ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    const int ncu = ofri_ctx_ncu(ctx);
     int nchunks = 3 * ncu / tiles_x;
     if (nchunks < 1) nchunks = 1;
     int chunk_rows = ceil_div(H, nchunks);

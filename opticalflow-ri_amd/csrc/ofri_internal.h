@@ -15,6 +15,7 @@ struct ofri_ctx {
     hipStream_t stream = nullptr;
     bool owns_stream = false;
     int hs_fuse = 0;                                   // sweeps per launch, 0 = automatic
+    int ncu = 0;                                       // compute units of the device (0 = not queried yet)
     std::map<size_t, std::vector<void *>> pool;        // free blocks by rounded size
     std::map<void *, size_t> live;                     // blocks handed out -> rounded size
     double *red_partials = nullptr;                    // device scratch for two-stage reductions
@@ -87,6 +88,16 @@ int ofri_cached_table(ofri_ctx *ctx, const std::string &key, const void *host, s
 static inline void *ofri_find_table(ofri_ctx *ctx, const std::string &key) {
     auto it = ctx->tables.find(key);
     return it == ctx->tables.end() ? nullptr : it->second;
+}
+
+// number of compute units of the context's device (queried once)
+static inline int ofri_ctx_ncu(ofri_ctx *ctx) {
+    if (ctx->ncu <= 0) {
+        hipDeviceProp_t prop;
+        ctx->ncu = (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0)
+                       ? prop.multiProcessorCount : 256;
+    }
+    return ctx->ncu;
 }
 
 static inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
