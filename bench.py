@@ -163,15 +163,29 @@ def main():
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = world * H * W * args.steps / dt / 1e6
-        # dominant kernel: the Jacobi sweep launches of the full-resolution level
+        # dominant kernel: the Jacobi sweep launches of the full-resolution level.  A Horn-Schunck call may use
+        # two kernels there (row-streaming pipeline for the multiples of 12 sweeps, tile kernel for the rest);
+        # the one with the larger share of the time is reported.
         full = [r for r in recs if r[3] == H and r[4] == W]
-        ms = sum(r[0] for r in full)
-        launches = sum(r[1] for r in full)
-        sweeps = sum(r[2] for r in full)
+        groups = {}
+        for r in full:
+            name = "k_hs_stream" if r[2] == 12 * r[1] else ("k_hs_sweep" if r[2] == r[1] else "k_hs_fused")
+            groups.setdefault(name, []).append(r)
+        kname, grp = max(groups.items(), key=lambda kv: sum(r[0] for r in kv[1])) if groups else ("none", [])
+        hs_ms_all = sum(r[0] for r in full)
+        ms = sum(r[0] for r in grp)
+        launches = sum(r[1] for r in grp)
+        sweeps = sum(r[2] for r in grp)
         per_launch_ms = ms / max(launches, 1)
         sweeps_per_launch = sweeps / max(launches, 1)
         alg_bytes = HS_BYTES_PER_PX_SWEEP * H * W * sweeps_per_launch
         achieved = alg_bytes / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
+        traffic = None
+        try:        # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                traffic = json.load(f).get("%s@%dx%d" % (kname, H, W))
+        except (OSError, ValueError):
+            pass
         result = {
             "metric": "Mpix/s per PIV frame pair (HS 100-iter @4096^2)",
             "value": value, "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -181,11 +195,13 @@ def main():
                                    "%d sweeps/level" % (H, W, args.niter),
                        "pairs_per_step_per_gpu": 1, "flow_gather": gather_note,
                        "hs_sweeps_per_launch": sweeps_per_launch},
-            "roofline": {"bound": "hbm", "kernel": "hs_jacobi_sweep@%dx%d" % (H, W), "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": "%s@%dx%d" % (kname, H, W), "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "launch_ms": per_launch_ms, "launches_timed": launches,
+                         "sweeps_per_launch": sweeps_per_launch,
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "hs_level2_share_of_step": (ms / args.steps) / ms_per_step if ms_per_step > 0 else None},
+                         "kernel_share_of_step": (ms / args.steps) / ms_per_step if ms_per_step > 0 else None,
+                         "hs_level2_share_of_step": (hs_ms_all / args.steps) / ms_per_step if ms_per_step > 0 else None},
         }
     if args.with_transfer and rank == 0 and world == 1:
         t = time.perf_counter()

@@ -2,35 +2,25 @@
 // Reference behaviour: src/HornSchunck.py:52-127 (HS_helper2, HS_helper, HS, computeDerivatives).
 #include "ofri_internal.h"
 #include "ofri_hs_math.h"
+#include "ofri_hs_stream.h"
 
 int ofri_norm_diff_dev(ofri_ctx *ctx, const float *a, const float *b, size_t n, int slot);
 int ofri_read_slots(ofri_ctx *ctx, int first, int count, double *out_host);
 
 // ---------------------------------------------------------------------------------------------
-// Derivatives.  scipy.ndimage.convolve with a 2x2 kernel w and 'mirror' border evaluates
-//   out[i,j] = w11*in[i,j] + w10*in[i,j+1] + w01*in[i+1,j] + w00*in[i+1,j+1]
-// in float64 and rounds to float32; the reference then adds the two images' results in float32.
-// All weights are +-0.25, so a float64 sum of the four taps scaled by 0.25 reproduces it exactly.
+// Derivatives (formula and citation: hs_derivs_at in ofri_hs_math.h).
 __global__ void k_hs_derivs(const float *__restrict__ P, const float *__restrict__ Q,   // P = first, Q = second
                             float *__restrict__ fx, float *__restrict__ fy, float *__restrict__ ft,
                             int H, int W) {
     int x = blockIdx.x * blockDim.x + threadIdx.x;
     int y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= W || y >= H) return;
-    int x1 = refl101(x + 1, W), y1 = refl101(y + 1, H);
-    size_t r0 = (size_t)y * W, r1 = (size_t)y1 * W;
-    double p00 = P[r0 + x], p01 = P[r0 + x1], p10 = P[r1 + x], p11 = P[r1 + x1];
-    double q00 = Q[r0 + x], q01 = Q[r0 + x1], q10 = Q[r1 + x], q11 = Q[r1 + x1];
-    float pfx = (float)(0.25 * (((p00 - p01) + p10) - p11));
-    float qfx = (float)(0.25 * (((q00 - q01) + q10) - q11));
-    float pfy = (float)(0.25 * (((p00 + p01) - p10) - p11));
-    float qfy = (float)(0.25 * (((q00 + q01) - q10) - q11));
-    float qft = (float)(0.25 * (((q00 + q01) + q10) + q11));
-    float pft = (float)(-0.25 * (((p00 + p01) + p10) + p11));
-    size_t o = r0 + x;
-    fx[o] = __fadd_rn(pfx, qfx);
-    fy[o] = __fadd_rn(pfy, qfy);
-    ft[o] = __fadd_rn(qft, pft);
+    float gx, gy, gt;
+    hs_derivs_at(P, Q, y, x, H, W, gx, gy, gt);
+    size_t o = (size_t)y * W + x;
+    fx[o] = gx;
+    fy[o] = gy;
+    ft[o] = gt;
 }
 
 extern "C" int ofri_hs_derivs(ofri_ctx *ctx, const float *first, const float *second,
@@ -171,15 +161,73 @@ int ofri_hs_fused_max_sweeps(void);
 int ofri_hs_fused_launch(ofri_ctx *ctx, const float *su, const float *sv, float *du, float *dv, const float *fx,
                          const float *fy, const float *ft, float a2, int T, int H, int W);
 
-int ofri_hs_stream_sweeps(void);
-int ofri_hs_stream_run(ofri_ctx *ctx, const float *Uin, const float *Vin, float *Uout, float *Vout, const float *fx,
-                       const float *fy, const float *ft, float a2, int niter, int H, int W, int *launches,
-                       hipEvent_t ev_begin, hipEvent_t ev_end);
+int ofri_hs_fused_launch_pitched(ofri_ctx *ctx, const float *su, const float *sv, float *du, float *dv, const float *fx,
+                                 const float *fy, const float *ft, float a2, int T, int H, int W, int pin, int pc, int pout);
 
 extern "C" int ofri_hs_set_fuse(ofri_ctx *ctx, int sweeps_per_launch) {
     OFRI_REQUIRE(ctx, "null context");
     OFRI_REQUIRE(sweeps_per_launch >= -1 && sweeps_per_launch <= 64, "sweeps_per_launch out of range");
     ctx->hs_fuse = sweeps_per_launch;
+    return OFRI_OK;
+}
+
+static int prof_begin(ofri_ctx *ctx, ofri_ctx::ProfRec &rec) {
+    if (!ctx->prof) return OFRI_OK;
+    OFRI_HIP(hipEventCreate(&rec.a)); OFRI_HIP(hipEventCreate(&rec.b));
+    OFRI_HIP(hipEventRecord(rec.a, ctx->stream));
+    return OFRI_OK;
+}
+static int prof_end(ofri_ctx *ctx, ofri_ctx::ProfRec &rec, int rows, int cols, int launches, int sweeps) {
+    if (!ctx->prof) return OFRI_OK;
+    OFRI_HIP(hipEventRecord(rec.b, ctx->stream));
+    rec.rows = rows; rec.cols = cols; rec.launches = launches; rec.sweeps = sweeps;
+    ctx->prof_recs.push_back(rec);
+    return OFRI_OK;
+}
+
+// How many of niter sweeps go through the row-streaming pipeline (12 per launch): all of them with
+// sweeps_per_launch = 16, the whole multiples of 12 on large fields in automatic mode, none otherwise.
+static int hs_stream_share(ofri_ctx *ctx, const void *const *ptrs, int nptrs, int niter, int rows, int cols) {
+    size_t bits = 0;
+    for (int i = 0; i < nptrs; ++i) bits |= (size_t)ptrs[i];
+    if ((bits & 15) != 0 || (cols & 3) != 0 || cols < 8 || niter <= 0) return 0;
+    const int per = ofri_hs_stream_sweeps();
+    if (ctx->hs_fuse == 16) return niter;
+    if (ctx->hs_fuse == 0 && ofri_hs_stream_pays(rows, cols) && niter >= 2 * per) return niter / per * per;
+    return 0;
+}
+
+// n_stream sweeps through the pipeline, the remaining niter - n_stream (fewer than 12) through the tile kernel
+// reading the pipeline's padded planes.  Coefficients: dense fx, fy, ft, or (fx == nullptr) differentiated from
+// the frames straight into the padded planes.  The padding pass is not part of the timing records.
+static int hs_stream_path(ofri_ctx *ctx, const float *Uin, const float *Vin, float *Uout, float *Vout, const float *fx,
+                          const float *fy, const float *ft, const float *first, const float *second, float a2, int niter,
+                          int n_stream, int rows, int cols) {
+    PoolBuf buf(ctx);
+    OFRI_TRY(buf.get(ofri_sl_bytes(rows, cols)));
+    OfriSlSet set;
+    ofri_sl_layout(buf.as<float>(), rows, cols, &set);
+    OFRI_TRY(ofri_sl_fill(ctx, set, Uin, Vin, fx, fy, ft, first, second, a2, rows, cols));
+    int rest = niter - n_stream, cur = 0, launches = 0;
+    ofri_ctx::ProfRec rec{};
+    OFRI_TRY(prof_begin(ctx, rec));
+    OFRI_TRY(ofri_sl_sweeps(ctx, set, n_stream, rest == 0, Uout, Vout, rows, cols, &cur, &launches));
+    OFRI_TRY(prof_end(ctx, rec, rows, cols, launches, n_stream));
+    if (rest > 0) {
+        const int Tmax = ofri_hs_fused_max_sweeps(), L = (rest + Tmax - 1) / Tmax;
+        ofri_ctx::ProfRec rec2{};
+        OFRI_TRY(prof_begin(ctx, rec2));
+        int remaining = rest;
+        for (int k = 0; k < L; ++k) {
+            const int T = remaining < Tmax ? remaining : Tmax;
+            const bool last = k == L - 1;
+            OFRI_TRY(ofri_hs_fused_launch_pitched(ctx, set.U[cur], set.V[cur], last ? Uout : set.U[cur ^ 1], last ? Vout : set.V[cur ^ 1],
+                                                  set.fx, set.fy, set.ft, a2, T, rows, cols, set.P, set.P, last ? cols : set.P));
+            cur ^= 1;
+            remaining -= T;
+        }
+        OFRI_TRY(prof_end(ctx, rec2, rows, cols, L, rest));
+    }
     return OFRI_OK;
 }
 
@@ -196,27 +244,10 @@ static int hs_iterate_io(ofri_ctx *ctx, const float *Uin, const float *Vin, floa
     const float a2 = alpha * alpha;         // alpha is a float32 in the reference's compiled signature
     const bool exact = ctx->hs_fuse == -1;  // -1: bit-exact restatement of scipy's float64 accumulation
     {
-        // sweeps_per_launch = 16 selects the row-streaming pipeline (12 sweeps per launch).  Opt-in: at 4096^2
-        // it runs 20.8 us per sweep against 22 us for the tile kernel, but a partial last launch costs a whole
-        // one, and smaller fields do not fill its row chunks.
         const void *q[7] = {Uin, Vin, Uout, Vout, fx, fy, ft};
-        size_t bits = 0;
-        for (int i = 0; i < 7; ++i) bits |= (size_t)q[i];
-        const bool can = (bits & 15) == 0 && (cols & 3) == 0 && cols >= 8;
-        if (can && ctx->hs_fuse == 16) {
-            ofri_ctx::ProfRec rec{};
-            if (ctx->prof) {
-                OFRI_HIP(hipEventCreate(&rec.a)); OFRI_HIP(hipEventCreate(&rec.b));
-            }
-            int launches = 0;
-            // the events bracket the sweep launches; the padding copies before them are not part of the record
-            OFRI_TRY(ofri_hs_stream_run(ctx, Uin, Vin, Uout, Vout, fx, fy, ft, a2, niter, rows, cols, &launches, rec.a, rec.b));
-            if (ctx->prof) {
-                rec.rows = rows; rec.cols = cols; rec.launches = launches; rec.sweeps = niter;
-                ctx->prof_recs.push_back(rec);
-            }
-            return OFRI_OK;
-        }
+        const int n_stream = hs_stream_share(ctx, q, 7, niter, rows, cols);
+        if (n_stream > 0)
+            return hs_stream_path(ctx, Uin, Vin, Uout, Vout, fx, fy, ft, nullptr, nullptr, a2, niter, n_stream, rows, cols);
     }
     PoolBuf tu(ctx), tv(ctx);
     OFRI_TRY(tu.get(bytes));
@@ -234,10 +265,7 @@ static int hs_iterate_io(ofri_ctx *ctx, const float *Uin, const float *Vin, floa
     // overwrite its own source runs one launch more through the scratch planes instead (final copy)
     const bool detour = inplace && ((L - 1) % 2 == 0);
     ofri_ctx::ProfRec rec{};
-    if (ctx->prof) {
-        OFRI_HIP(hipEventCreate(&rec.a)); OFRI_HIP(hipEventCreate(&rec.b));
-        OFRI_HIP(hipEventRecord(rec.a, ctx->stream));
-    }
+    OFRI_TRY(prof_begin(ctx, rec));
     const float *su = Uin, *sv = Vin;
     int remaining = niter;
     for (int k = 0; k < L; ++k) {
@@ -250,11 +278,7 @@ static int hs_iterate_io(ofri_ctx *ctx, const float *Uin, const float *Vin, floa
         su = du; sv = dv;
         remaining -= T;
     }
-    if (ctx->prof) {
-        OFRI_HIP(hipEventRecord(rec.b, ctx->stream));
-        rec.rows = rows; rec.cols = cols; rec.launches = L; rec.sweeps = niter;
-        ctx->prof_recs.push_back(rec);
-    }
+    OFRI_TRY(prof_end(ctx, rec, rows, cols, L, niter));
     if (su != Uout) {
         OFRI_HIP(hipMemcpyAsync(Uout, su, bytes, hipMemcpyDeviceToDevice, ctx->stream));
         OFRI_HIP(hipMemcpyAsync(Vout, sv, bytes, hipMemcpyDeviceToDevice, ctx->stream));
@@ -279,11 +303,19 @@ extern "C" int ofri_hs_compute(ofri_ctx *ctx, const float *frame0, const float *
     OFRI_REQUIRE(U_out != U_in && V_out != V_in && U_out != V_out, "output must not alias input");
     OFRI_REQUIRE(rows > 0 && cols > 0 && niter >= 0, "bad shape or niter");
     size_t n = (size_t)rows * cols, bytes = n * sizeof(float);
-    PoolBuf fx(ctx), fy(ctx), ft(ctx);
-    OFRI_TRY(fx.get(bytes)); OFRI_TRY(fy.get(bytes)); OFRI_TRY(ft.get(bytes));
     // HS(im2=frame0, im1=frame1) -> computeDerivatives(im1=frame1, im2=frame0)   (HornSchunck.py:37,73,84)
-    OFRI_TRY(ofri_hs_derivs(ctx, frame1, frame0, fx.as<float>(), fy.as<float>(), ft.as<float>(), rows, cols));
-    OFRI_TRY(hs_iterate_io(ctx, U_in, V_in, U_out, V_out, fx.as<float>(), fy.as<float>(), ft.as<float>(), alpha, niter, rows, cols));
+    const void *q[6] = {frame0, frame1, U_in, V_in, U_out, V_out};
+    const int n_stream = hs_stream_share(ctx, q, 6, niter, rows, cols);
+    if (n_stream > 0) {
+        // large field: the derivatives go straight into the pipeline's padded planes, no dense copy of them exists
+        OFRI_TRY(hs_stream_path(ctx, U_in, V_in, U_out, V_out, nullptr, nullptr, nullptr, frame1, frame0, alpha * alpha, niter,
+                                n_stream, rows, cols));
+    } else {
+        PoolBuf fx(ctx), fy(ctx), ft(ctx);
+        OFRI_TRY(fx.get(bytes)); OFRI_TRY(fy.get(bytes)); OFRI_TRY(ft.get(bytes));
+        OFRI_TRY(ofri_hs_derivs(ctx, frame1, frame0, fx.as<float>(), fy.as<float>(), ft.as<float>(), rows, cols));
+        OFRI_TRY(hs_iterate_io(ctx, U_in, V_in, U_out, V_out, fx.as<float>(), fy.as<float>(), ft.as<float>(), alpha, niter, rows, cols));
+    }
     if (err_host) {
         OFRI_TRY(ofri_norm_diff_dev(ctx, U_out, U_in, n, 0));
         OFRI_TRY(ofri_norm_diff_dev(ctx, V_out, V_in, n, 1));

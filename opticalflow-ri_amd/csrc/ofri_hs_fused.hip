@@ -88,7 +88,7 @@ __device__ __forceinline__ void ft_sweep(float4 (&edge)[2][FT_BANDS + 2][2][2][3
 __global__ void __launch_bounds__(256, 2)
 k_hs_fused(const float *__restrict__ U, const float *__restrict__ V, const float *__restrict__ fx,
            const float *__restrict__ fy, const float *__restrict__ ft, float *__restrict__ Un,
-           float *__restrict__ Vn, float a2, int H, int W, int T, int tiles_x, int ntiles) {
+           float *__restrict__ Vn, float a2, int H, int W, int T, int tiles_x, int ntiles, int pin, int pc, int pout) {
     // [buffer][slot][top/bottom][U/V][lane]; slot b+1 belongs to band b, slots 0 and FT_BANDS+1 are never written
     __shared__ float4 edge[2][FT_BANDS + 2][2][2][32];
     __shared__ float4 ftile[FT_RY][32];          // ft of the region: read-only after the load, kept out of registers
@@ -108,22 +108,23 @@ k_hs_fused(const float *__restrict__ U, const float *__restrict__ V, const float
     for (int r = 0; r < FT_S; ++r) {
         int y = gyb + r;
         if (xin && y >= 0 && y < H) {
-            size_t o = (size_t)y * W + gx0;
+            const size_t o = (size_t)y * pin + gx0, oc = (size_t)y * pc + gx0;
             float4 a = *reinterpret_cast<const float4 *>(U + o), bb = *reinterpret_cast<const float4 *>(V + o);
-            float4 c = *reinterpret_cast<const float4 *>(fx + o), d = *reinterpret_cast<const float4 *>(fy + o);
-            float4 e = *reinterpret_cast<const float4 *>(ft + o);
+            float4 c = *reinterpret_cast<const float4 *>(fx + oc), d = *reinterpret_cast<const float4 *>(fy + oc);
+            float4 e = *reinterpret_cast<const float4 *>(ft + oc);
             cu[r][0] = a.x; cu[r][1] = a.y; cu[r][2] = a.z; cu[r][3] = a.w;
             cv[r][0] = bb.x; cv[r][1] = bb.y; cv[r][2] = bb.z; cv[r][3] = bb.w;
             gx[r][0] = c.x; gx[r][1] = c.y; gx[r][2] = c.z; gx[r][3] = c.w;
             gy[r][0] = d.x; gy[r][1] = d.y; gy[r][2] = d.z; gy[r][3] = d.w;
             ftile[band * FT_S + r][l32] = e;
         } else {
-            size_t ro = (size_t)refl101_any(y, H) * W;
+            const int ry = refl101_any(y, H);
+            const size_t ro = (size_t)ry * pin, rc = (size_t)ry * pc;
             float e[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                size_t o = ro + refl101_any(gx0 + k, W);
-                cu[r][k] = U[o]; cv[r][k] = V[o]; gx[r][k] = fx[o]; gy[r][k] = fy[o]; e[k] = ft[o];
+                const int rx = refl101_any(gx0 + k, W);
+                cu[r][k] = U[ro + rx]; cv[r][k] = V[ro + rx]; gx[r][k] = fx[rc + rx]; gy[r][k] = fy[rc + rx]; e[k] = ft[rc + rx];
             }
             ftile[band * FT_S + r][l32] = make_float4(e[0], e[1], e[2], e[3]);
         }
@@ -160,7 +161,7 @@ k_hs_fused(const float *__restrict__ U, const float *__restrict__ V, const float
         for (int r = 0; r < FT_S; ++r) {
             int y = gyb + r;
             if (y < H) {
-                size_t o = (size_t)y * W + gx0;
+                size_t o = (size_t)y * pout + gx0;
                 *reinterpret_cast<float4 *>(Un + o) = make_float4(cu[r][0], cu[r][1], cu[r][2], cu[r][3]);
                 *reinterpret_cast<float4 *>(Vn + o) = make_float4(cv[r][0], cv[r][1], cv[r][2], cv[r][3]);
             }
@@ -176,11 +177,17 @@ bool ofri_hs_fused_ok(const void *const *ptrs, int nptrs, int H, int W) {
 }
 int ofri_hs_fused_max_sweeps(void) { return FT_HALO; }
 
-// One launch: T <= FT_HALO sweeps from (su, sv) into (du, dv); source and destination must differ.
-int ofri_hs_fused_launch(ofri_ctx *ctx, const float *su, const float *sv, float *du, float *dv, const float *fx,
-                         const float *fy, const float *ft, float a2, int T, int H, int W) {
+// One launch: T <= FT_HALO sweeps from (su, sv) into (du, dv); source and destination must differ.  Every
+// pointer is at pixel (0,0) of its plane; pin, pc, pout are the row pitches (in floats, multiples of 4) of the
+// source, coefficient and destination planes.
+int ofri_hs_fused_launch_pitched(ofri_ctx *ctx, const float *su, const float *sv, float *du, float *dv, const float *fx,
+                                 const float *fy, const float *ft, float a2, int T, int H, int W, int pin, int pc, int pout) {
     const int tiles_x = ceil_div(W, FT_OX), tiles_y = ceil_div(H, FT_OY), ntiles = tiles_x * tiles_y;
-    k_hs_fused<<<ntiles, 256, 0, ctx->stream>>>(su, sv, fx, fy, ft, du, dv, a2, H, W, T, tiles_x, ntiles);
+    k_hs_fused<<<ntiles, 256, 0, ctx->stream>>>(su, sv, fx, fy, ft, du, dv, a2, H, W, T, tiles_x, ntiles, pin, pc, pout);
     OFRI_LAUNCH_CHECK();
     return OFRI_OK;
+}
+int ofri_hs_fused_launch(ofri_ctx *ctx, const float *su, const float *sv, float *du, float *dv, const float *fx,
+                         const float *fy, const float *ft, float a2, int T, int H, int W) {
+    return ofri_hs_fused_launch_pitched(ctx, su, sv, du, dv, fx, fy, ft, a2, T, H, W, W, W, W);
 }

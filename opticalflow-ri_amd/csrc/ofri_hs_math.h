@@ -24,3 +24,26 @@ __device__ __forceinline__ void hs_update(float ua, float va, float fx, float fy
     un = fmaf(-fx, der, ua);
     vn = fmaf(-fy, der, va);
 }
+
+// The derivative cube at pixel (y, x) (reference computeDerivatives, src/HornSchunck.py:107-127).
+// scipy.ndimage.convolve with a 2x2 kernel w and 'mirror' border evaluates
+//   out[i,j] = w11*in[i,j] + w10*in[i,j+1] + w01*in[i+1,j] + w00*in[i+1,j+1]
+// in float64 and rounds to float32; the reference then adds the two images' results in float32.
+// All weights are +-0.25, so a float64 sum of the four taps scaled by 0.25 reproduces it exactly.
+// P = first image, Q = second image, dense with W columns.
+__device__ __forceinline__ void hs_derivs_at(const float *__restrict__ P, const float *__restrict__ Q, int y, int x, int H, int W,
+                                             float &fx, float &fy, float &ft) {
+    const int x1 = x + 1 < W ? x + 1 : (W > 1 ? W - 2 : 0), y1 = y + 1 < H ? y + 1 : (H > 1 ? H - 2 : 0);   // reflect-101
+    const size_t r0 = (size_t)y * W, r1 = (size_t)y1 * W;
+    const double p00 = P[r0 + x], p01 = P[r0 + x1], p10 = P[r1 + x], p11 = P[r1 + x1];
+    const double q00 = Q[r0 + x], q01 = Q[r0 + x1], q10 = Q[r1 + x], q11 = Q[r1 + x1];
+    const float pfx = (float)(0.25 * (((p00 - p01) + p10) - p11));
+    const float qfx = (float)(0.25 * (((q00 - q01) + q10) - q11));
+    const float pfy = (float)(0.25 * (((p00 + p01) - p10) - p11));
+    const float qfy = (float)(0.25 * (((q00 + q01) - q10) - q11));
+    const float qft = (float)(0.25 * (((q00 + q01) + q10) + q11));
+    const float pft = (float)(-0.25 * (((p00 + p01) + p10) + p11));
+    fx = __fadd_rn(pfx, qfx);
+    fy = __fadd_rn(pfy, qfy);
+    ft = __fadd_rn(qft, pft);
+}

@@ -16,6 +16,7 @@
 // result is bit-identical to the other Horn-Schunck kernels.
 #include "ofri_internal.h"
 #include "ofri_hs_math.h"
+#include "ofri_hs_stream.h"
 
 #define SL_NL 12                         // sweeps per launch = padding
 #define SL_NS (SL_NL / 2)                // pipeline stages
@@ -45,7 +46,8 @@ struct SlPlanes { const float *U, *V, *fx, *fy, *ft, *rd; };   // padded planes,
 struct SlRow { float u[4], v[4]; };                            // a lane's four pixels of one row
 struct SlCoef { float4 fx, fy, ft, rd; };
 
-// one sweep of a row: a = row above, c = the row, b = row below; pass = copy the row instead
+// one sweep of a row: a = row above, c = the row, b = row below; pass (only when !FULL) = copy the row instead
+template <bool FULL>
 __device__ __forceinline__ SlRow sl_sweep(const SlRow &a, const SlRow &c, const SlRow &b, const SlCoef &g, bool pass) {
     const float gx[4] = {g.fx.x, g.fx.y, g.fx.z, g.fx.w}, gy[4] = {g.fy.x, g.fy.y, g.fy.z, g.fy.w};
     const float gt[4] = {g.ft.x, g.ft.y, g.ft.z, g.ft.w}, rd[4] = {g.rd.x, g.rd.y, g.rd.z, g.rd.w};
@@ -65,7 +67,7 @@ __device__ __forceinline__ SlRow sl_sweep(const SlRow &a, const SlRow &c, const 
         float ua = hs_avg(su[k], qu[p], qu[q]);
         float va = hs_avg(sv[k], qv[p], qv[q]);
         hs_update(ua, va, gx[k], gy[k], gt[k], rd[k], o.u[k], o.v[k]);
-        if (pass) { o.u[k] = c.u[k]; o.v[k] = c.v[k]; }
+        if (!FULL && pass) { o.u[k] = c.u[k]; o.v[k] = c.v[k]; }
     }
     return o;
 }
@@ -79,6 +81,7 @@ struct SlStage {                 // registers of one pipeline stage (one lane)
 };
 
 // one step of a stage: first sweep at row rA, second sweep at row rA-1
+template <bool FULL>
 __device__ __forceinline__ void sl_stage_step(SlStage &st, float4 (&ring)[SL_NS][2][2][32], float4 (&coef)[SL_CR][4][32],
                                               int stage, int l, bool passA, bool passB, int ya, int yb, bool store_lane,
                                               int x0, float *__restrict__ Uo, float *__restrict__ Vo, long long opitch) {
@@ -90,8 +93,8 @@ __device__ __forceinline__ void sl_stage_step(SlStage &st, float4 (&ring)[SL_NS]
     SlRow nw;
     nw.u[0] = nu4.x; nw.u[1] = nu4.y; nw.u[2] = nu4.z; nw.u[3] = nu4.w;
     nw.v[0] = nv4.x; nw.v[1] = nv4.y; nw.v[2] = nv4.z; nw.v[3] = nv4.w;
-    const SlRow mid2 = sl_sweep(st.in0, st.in1, nw, g, passA);                  // row rA of the first sweep
-    const SlRow out = sl_sweep(st.mid0, st.mid1, mid2, st.gprev, passB);        // row rA-1 of the second sweep
+    const SlRow mid2 = sl_sweep<FULL>(st.in0, st.in1, nw, g, passA);                  // row rA of the first sweep
+    const SlRow out = sl_sweep<FULL>(st.mid0, st.mid1, mid2, st.gprev, passB);        // row rA-1 of the second sweep
     const int rB = st.rA - 1;
     if (stage < SL_NS - 1) {
         ring[stage + 1][rB & 1][0][l] = make_float4(out.u[0], out.u[1], out.u[2], out.u[3]);
@@ -107,6 +110,8 @@ __device__ __forceinline__ void sl_stage_step(SlStage &st, float4 (&ring)[SL_NS]
     ++st.rA;
 }
 
+// FULL: all SL_NL sweeps are wanted (no copy-through selects in the inner loop)
+template <bool FULL>
 __global__ void __launch_bounds__(SL_THREADS)
 k_hs_stream(SlPlanes in, float *__restrict__ Uo, float *__restrict__ Vo, long long opitch, int P, int H, int W, int T,
             int tiles_x, int chunk_rows) {
@@ -174,22 +179,36 @@ k_hs_stream(SlPlanes in, float *__restrict__ Uo, float *__restrict__ Vo, long lo
         const bool passA = 2 * stage >= T, passB = 2 * stage + 1 >= T;    // fewer than 16 sweeps asked: copy rows through
         const bool store_lane = l >= SL_NL / 4 && l < 32 - SL_NL / 4 && (x0 + 4 * l) < W;
         // six steps per round (NS is a multiple): the row registers rotate by renaming instead of moves
-#define SL_STEP() sl_stage_step(st, ring, coef, stage, l, passA, passB, ya, yb, store_lane, x0, Uo, Vo, opitch); __syncthreads();
+#define SL_STEP() sl_stage_step<FULL>(st, ring, coef, stage, l, passA, passB, ya, yb, store_lane, x0, Uo, Vo, opitch); __syncthreads();
         for (int t = 0; t < NS; t += SL_PF) { SL_STEP() SL_STEP() SL_STEP() SL_STEP() SL_STEP() SL_STEP() }
 #undef SL_STEP
     }
 }
 
 // ---- padded copies ------------------------------------------------------------------------------------
-// dst (pointer at image (0,0), pitch P) receives src mirrored into a border of SL_NL pixels; mode 1 writes
-// 1/(alpha^2 + fx^2 + fy^2) instead (src = fx, src2 = fy)
-__global__ void k_sl_pad(const float *__restrict__ src, const float *__restrict__ src2, float *__restrict__ dst, int P, int H,
-                         int W, int mode, float a2) {
-    int x = blockIdx.x * blockDim.x + threadIdx.x - SL_NL;
-    int y = blockIdx.y * blockDim.y + threadIdx.y - SL_NL;
-    if (x >= W + SL_NL || y >= H + SL_NL) return;
-    size_t s = (size_t)sl_refl(y, H) * W + sl_refl(x, W);
-    dst[(long long)y * P + x] = mode ? hs_rden(src[s], src2[s], a2) : src[s];
+// Fill of a plane set (ofri_hs_stream.h): the image mirrored into a border of SL_NL pixels, 1/(alpha^2 + fx^2 + fy^2)
+// for rd, zeros in the columns between the border and the pitch (the last strip reads them; they only reach
+// pixels that are never stored, but must be finite).  The second U, V pair gets those zeros too.
+// FRAMES: fx, fy, ft are differentiated on the spot from the two frames (ca = first, cb = second image of
+// computeDerivatives); otherwise ca, cb, cc are dense fx, fy, ft.
+template <bool FRAMES>
+__global__ void k_sl_fill(const float *__restrict__ U, const float *__restrict__ V, const float *__restrict__ ca,
+                          const float *__restrict__ cb, const float *__restrict__ cc, OfriSlSet o, int H, int W, float a2) {
+    const int P = o.P;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x - SL_NL;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y - SL_NL;
+    if (x >= P - SL_NL || y >= H + SL_NL) return;
+    const long long d = (long long)y * P + x;
+    if (x >= W + SL_NL) {
+        o.U[0][d] = 0.f; o.V[0][d] = 0.f; o.fx[d] = 0.f; o.fy[d] = 0.f; o.ft[d] = 0.f; o.rd[d] = 0.f; o.U[1][d] = 0.f; o.V[1][d] = 0.f;
+        return;
+    }
+    const int sy = sl_refl(y, H), sx = sl_refl(x, W);
+    const size_t s = (size_t)sy * W + sx;
+    float gx, gy, gt;
+    if (FRAMES) hs_derivs_at(ca, cb, sy, sx, H, W, gx, gy, gt);
+    else { gx = ca[s]; gy = cb[s]; gt = cc[s]; }
+    o.U[0][d] = U[s]; o.V[0][d] = V[s]; o.fx[d] = gx; o.fy[d] = gy; o.ft[d] = gt; o.rd[d] = hs_rden(gx, gy, a2);
 }
 // refresh the mirrored border of a padded plane from its interior
 __global__ void k_sl_repad(float *__restrict__ U, float *__restrict__ V, int P, int H, int W) {
@@ -214,57 +233,61 @@ __global__ void k_sl_repad(float *__restrict__ U, float *__restrict__ V, int P, 
 }
 
 int ofri_hs_stream_sweeps(void) { return SL_NL; }
+// worth it where the row chunks are long against the pipeline's fill (about 4096 x 3072 pixels and up)
+bool ofri_hs_stream_pays(int H, int W) { return (long long)H * W >= 12000000LL && (W & 3) == 0; }
 
-// niter sweeps from dense (Uin, Vin) to dense (Uout, Vout); all pointers 16-byte aligned, W % 4 == 0
-int ofri_hs_stream_run(ofri_ctx *ctx, const float *Uin, const float *Vin, float *Uout, float *Vout, const float *fx,
-                       const float *fy, const float *ft, float a2, int niter, int H, int W, int *launches,
-                       hipEvent_t ev_begin, hipEvent_t ev_end) {
+size_t ofri_sl_bytes(int H, int W) {
+    const int tiles_x = ceil_div(W, SL_OX), P = tiles_x * SL_OX + 2 * SL_NL;
+    return 8 * ((size_t)H + 2 * SL_NL) * P * sizeof(float);
+}
+void ofri_sl_layout(float *base, int H, int W, OfriSlSet *s) {
     const int tiles_x = ceil_div(W, SL_OX);
-    const int P = tiles_x * SL_OX + 2 * SL_NL;                 // multiple of 4; covers the last strip
-    const size_t rows = (size_t)H + 2 * SL_NL, plane = rows * P;
-    PoolBuf buf(ctx);
-    OFRI_TRY(buf.get(8 * plane * sizeof(float)));
-    float *base = buf.as<float>();
-    OFRI_HIP(hipMemsetAsync(base, 0, 8 * plane * sizeof(float), ctx->stream));   // columns past W+16 stay finite
-    auto at00 = [&](int k) { return base + k * plane + (size_t)SL_NL * P + SL_NL; };
-    float *pU[2] = {at00(0), at00(2)}, *pV[2] = {at00(1), at00(3)};
-    float *pfx = at00(4), *pfy = at00(5), *pft = at00(6), *prd = at00(7);
-    {
-        dim3 b(64, 4), g(ceil_div(W + 2 * SL_NL, 64), ceil_div(H + 2 * SL_NL, 4));
-        k_sl_pad<<<g, b, 0, ctx->stream>>>(Uin, nullptr, pU[0], P, H, W, 0, a2);
-        k_sl_pad<<<g, b, 0, ctx->stream>>>(Vin, nullptr, pV[0], P, H, W, 0, a2);
-        k_sl_pad<<<g, b, 0, ctx->stream>>>(fx, nullptr, pfx, P, H, W, 0, a2);
-        k_sl_pad<<<g, b, 0, ctx->stream>>>(fy, nullptr, pfy, P, H, W, 0, a2);
-        k_sl_pad<<<g, b, 0, ctx->stream>>>(ft, nullptr, pft, P, H, W, 0, a2);
-        k_sl_pad<<<g, b, 0, ctx->stream>>>(fx, fy, prd, P, H, W, 1, a2);
-        OFRI_LAUNCH_CHECK();
-    }
+    s->P = tiles_x * SL_OX + 2 * SL_NL;                        // multiple of 4; covers the last strip
+    const size_t plane = ((size_t)H + 2 * SL_NL) * s->P;
+    auto at00 = [&](int k) { return base + k * plane + (size_t)SL_NL * s->P + SL_NL; };
+    s->U[0] = at00(0); s->V[0] = at00(1); s->U[1] = at00(2); s->V[1] = at00(3);
+    s->fx = at00(4); s->fy = at00(5); s->ft = at00(6); s->rd = at00(7);
+}
+// U, V dense; coefficients either dense (fx, fy, ft) or, with fx == nullptr, differentiated from the frames
+int ofri_sl_fill(ofri_ctx *ctx, const OfriSlSet &s, const float *U, const float *V, const float *fx, const float *fy,
+                 const float *ft, const float *first, const float *second, float a2, int H, int W) {
+    dim3 b(64, 4), g(ceil_div(s.P, 64), ceil_div(H + 2 * SL_NL, 4));
+    if (fx) k_sl_fill<false><<<g, b, 0, ctx->stream>>>(U, V, fx, fy, ft, s, H, W, a2);
+    else k_sl_fill<true><<<g, b, 0, ctx->stream>>>(U, V, first, second, nullptr, s, H, W, a2);
+    OFRI_LAUNCH_CHECK();
+    return OFRI_OK;
+}
+// n sweeps starting from the pair *cur of the set.  to_dense: the last launch stores into (Uout, Vout), dense
+// with W columns; otherwise the result stays in the set and *cur names its pair (border not refreshed).
+int ofri_sl_sweeps(ofri_ctx *ctx, const OfriSlSet &s, int n, bool to_dense, float *Uout, float *Vout, int H, int W,
+                   int *cur, int *launches) {
+    const int tiles_x = ceil_div(W, SL_OX), P = s.P;
     // three workgroups per CU (48 KB of LDS each): as many row chunks as fill the chip once
     const int ncu = ofri_ctx_ncu(ctx);
     int nchunks = 3 * ncu / tiles_x;
     if (nchunks < 1) nchunks = 1;
     int chunk_rows = ceil_div(H, nchunks);
     nchunks = ceil_div(H, chunk_rows);
-    const int L = ceil_div(niter, SL_NL);
-    int remaining = niter, cur = 0;
-    if (ev_begin) OFRI_HIP(hipEventRecord(ev_begin, ctx->stream));
+    const int L = ceil_div(n, SL_NL);
+    int remaining = n, c = *cur;
     for (int k = 0; k < L; ++k) {
         const int T = remaining < SL_NL ? remaining : SL_NL;
-        const bool last = k == L - 1;
-        SlPlanes in{pU[cur], pV[cur], pfx, pfy, pft, prd};
-        float *uo = last ? Uout : pU[cur ^ 1], *vo = last ? Vout : pV[cur ^ 1];
-        k_hs_stream<<<tiles_x * nchunks, SL_THREADS, 0, ctx->stream>>>(in, uo, vo, last ? (long long)W : (long long)P, P, H, W, T,
-                                                                       tiles_x, chunk_rows);
+        const bool last = k == L - 1, dense = last && to_dense;
+        SlPlanes in{s.U[c], s.V[c], s.fx, s.fy, s.ft, s.rd};
+        float *uo = dense ? Uout : s.U[c ^ 1], *vo = dense ? Vout : s.V[c ^ 1];
+        const long long opitch = dense ? (long long)W : (long long)P;
+        if (T == SL_NL) k_hs_stream<true><<<tiles_x * nchunks, SL_THREADS, 0, ctx->stream>>>(in, uo, vo, opitch, P, H, W, T, tiles_x, chunk_rows);
+        else k_hs_stream<false><<<tiles_x * nchunks, SL_THREADS, 0, ctx->stream>>>(in, uo, vo, opitch, P, H, W, T, tiles_x, chunk_rows);
         OFRI_LAUNCH_CHECK();
         if (!last) {
-            long long n = 2LL * SL_NL * (W + 2 * SL_NL) + (long long)H * 2 * SL_NL;
-            k_sl_repad<<<(int)((n + 255) / 256), 256, 0, ctx->stream>>>(uo, vo, P, H, W);
+            long long m = 2LL * SL_NL * (W + 2 * SL_NL) + (long long)H * 2 * SL_NL;
+            k_sl_repad<<<(int)((m + 255) / 256), 256, 0, ctx->stream>>>(uo, vo, P, H, W);
             OFRI_LAUNCH_CHECK();
         }
-        cur ^= 1;
+        if (!dense) c ^= 1;
         remaining -= T;
     }
-    if (ev_end) OFRI_HIP(hipEventRecord(ev_end, ctx->stream));
+    *cur = c;
     if (launches) *launches = L;
     return OFRI_OK;
 }
