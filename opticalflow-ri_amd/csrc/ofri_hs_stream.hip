@@ -83,8 +83,8 @@ struct SlStage {                 // registers of one pipeline stage (one lane)
 // one step of a stage: first sweep at row rA, second sweep at row rA-1
 template <bool FULL>
 __device__ __forceinline__ void sl_stage_step(SlStage &st, float4 (&ring)[SL_NS][2][2][32], float4 (&coef)[SL_CR][4][32],
-                                              int stage, int l, bool passA, bool passB, int ya, int yb, bool store_lane,
-                                              int x0, float *__restrict__ Uo, float *__restrict__ Vo, long long opitch) {
+                                              int stage, int l, bool passA, bool passB, bool store_lane, int lane_off,
+                                              float *__restrict__ rowU, float *__restrict__ rowV, bool row_ok) {
     // newest input row rA+1, written one step ago
     const float4 nu4 = ring[stage][(st.rA + 1) & 1][0][l], nv4 = ring[stage][(st.rA + 1) & 1][1][l];
     SlCoef g;
@@ -99,10 +99,10 @@ __device__ __forceinline__ void sl_stage_step(SlStage &st, float4 (&ring)[SL_NS]
     if (stage < SL_NS - 1) {
         ring[stage + 1][rB & 1][0][l] = make_float4(out.u[0], out.u[1], out.u[2], out.u[3]);
         ring[stage + 1][rB & 1][1][l] = make_float4(out.v[0], out.v[1], out.v[2], out.v[3]);
-    } else if (store_lane && rB >= ya && rB < yb) {
-        const long long o = (long long)rB * opitch + x0 + 4 * l;
-        *reinterpret_cast<float4 *>(Uo + o) = make_float4(out.u[0], out.u[1], out.u[2], out.u[3]);
-        *reinterpret_cast<float4 *>(Vo + o) = make_float4(out.v[0], out.v[1], out.v[2], out.v[3]);
+    } else if (store_lane && row_ok) {
+        // rowU, rowV: the output row of this step (the same for the whole workgroup, so its address is scalar work)
+        *reinterpret_cast<float4 *>(rowU + lane_off) = make_float4(out.u[0], out.u[1], out.u[2], out.u[3]);
+        *reinterpret_cast<float4 *>(rowV + lane_off) = make_float4(out.v[0], out.v[1], out.v[2], out.v[3]);
     }
     st.in0 = st.in1; st.in1 = nw;
     st.mid0 = st.mid1; st.mid1 = mid2;
@@ -131,17 +131,19 @@ k_hs_stream(SlPlanes in, float *__restrict__ Uo, float *__restrict__ Vo, long lo
     // both execute one barrier per step, NS in all.
     if (tid >= SL_NS * 32) {
         // ---- loader wavefront: lanes 0-31 carry U, fx, ft; lanes 32-63 carry V, fy, 1/den ------------------
-        const int lj = tid & 31, lcol = 4 * lj, lset = (tid >> 5) & 1;
-        const float *pa = lset ? in.V : in.U, *pb = lset ? in.fy : in.fx, *pc = lset ? in.rd : in.ft;
+        // V, fy and 1/den lie one plane after U, fx and ft, so a row's address is a scalar base plus a per-lane
+        // byte offset below 2^32: no vector arithmetic per load
+        const int lj = tid & 31, lset = (tid >> 5) & 1;
+        const unsigned lane_bytes = (unsigned)((x0 + SL_NL + 4 * lj) * 4) + (lset ? (unsigned)((in.V - in.U) * 4) : 0u);
         int lslot = (rho0 + 64 * SL_CR) % SL_CR;               // slot of the row written next
         // rows in flight: named registers (an array here ends up in scratch memory, which serialises the prefetch)
-#define SL_LOAD(U_, ROW_)                                                          \
-    {                                                                              \
-        const int row = min((ROW_), H + SL_NL - 1);                                \
-        const long long o = (long long)row * P + x0 + lcol;                        \
-        qa##U_ = *reinterpret_cast<const float4 *>(pa + o);                        \
-        qb##U_ = *reinterpret_cast<const float4 *>(pb + o);                        \
-        qc##U_ = *reinterpret_cast<const float4 *>(pc + o);                        \
+#define SL_LOAD(U_, ROW_)                                                                          \
+    {                                                                                              \
+        const int row = min((ROW_), H + SL_NL - 1);                                                \
+        const long long o = (long long)row * P - SL_NL;        /* scalar: start of the padded row */ \
+        qa##U_ = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(in.U + o) + lane_bytes);  \
+        qb##U_ = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(in.fx + o) + lane_bytes); \
+        qc##U_ = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(in.ft + o) + lane_bytes); \
     }
         // the compiler must keep the first fill in program order (oldest load = first row consumed), or it has
         // to wait for every load in flight at the top of each round
@@ -178,9 +180,16 @@ k_hs_stream(SlPlanes in, float *__restrict__ Uo, float *__restrict__ Vo, long lo
         st.cslot = (st.rA + 64 * SL_CR) % SL_CR;
         const bool passA = 2 * stage >= T, passB = 2 * stage + 1 >= T;    // fewer than 16 sweeps asked: copy rows through
         const bool store_lane = l >= SL_NL / 4 && l < 32 - SL_NL / 4 && (x0 + 4 * l) < W;
+        const int lane_off = x0 + 4 * l;
         // six steps per round (NS is a multiple): the row registers rotate by renaming instead of moves
-#define SL_STEP() sl_stage_step<FULL>(st, ring, coef, stage, l, passA, passB, ya, yb, store_lane, x0, Uo, Vo, opitch); __syncthreads();
-        for (int t = 0; t < NS; t += SL_PF) { SL_STEP() SL_STEP() SL_STEP() SL_STEP() SL_STEP() SL_STEP() }
+#define SL_STEP(U_)                                                                                                   \
+    {                                                                                                                 \
+        const int ro = rho0 - SL_LAG + t + (U_);          /* row the last stage finishes at this step */              \
+        sl_stage_step<FULL>(st, ring, coef, stage, l, passA, passB, store_lane, lane_off, Uo + (long long)ro * opitch,  \
+                            Vo + (long long)ro * opitch, ro >= ya && ro < yb);                                        \
+        __syncthreads();                                                                                              \
+    }
+        for (int t = 0; t < NS; t += SL_PF) { SL_STEP(0) SL_STEP(1) SL_STEP(2) SL_STEP(3) SL_STEP(4) SL_STEP(5) }
 #undef SL_STEP
     }
 }
