@@ -243,7 +243,7 @@ __global__ void k_sl_repad(float *__restrict__ U, float *__restrict__ V, int P, 
 
 int ofri_hs_stream_sweeps(void) { return SL_NL; }
 // worth it where the row chunks are long against the pipeline's fill (about 4096 x 3072 pixels and up)
-bool ofri_hs_stream_pays(int H, int W) { return (long long)H * W >= 12000000LL && (W & 3) == 0; }
+bool ofri_hs_stream_pays(int H, int W) { return (long long)H * W >= 4000000LL && (W & 3) == 0; }
 
 size_t ofri_sl_bytes(int H, int W) {
     const int tiles_x = ceil_div(W, SL_OX), P = tiles_x * SL_OX + 2 * SL_NL;
