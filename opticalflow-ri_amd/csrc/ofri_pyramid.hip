@@ -228,13 +228,13 @@ static int get_spline_eval(ofri_ctx *ctx, int n, int N, SplineEvalTable *t) {
 
 // The system is strictly diagonally dominant: a perturbation of the forward recurrence shrinks by
 // 1/(4 - cp) ~ 0.268 per step (and of the back substitution by cp ~ 0.268), so a line can be cut into
-// chunks that each start SP_WARM = 48 samples early from a zero state; the start-up error is below
-// 0.268^48 ~ 4e-28 of the values, far under float64 rounding.  Chunks run in parallel:
+// chunks that each start SP_WARM = 40 samples early from a zero state; the start-up error is below
+// 0.268^40 ~ 1e-23 of the values, far under float64 rounding.  Chunks run in parallel:
 // thread = (line, chunk).  Arrays are (n, L): sample k of line l at k*L + l, so consecutive threads
 // (consecutive lines) touch consecutive addresses.  Loads are issued SP_BLK steps ahead of the
 // dependent recurrence.
-#define SP_CHUNK 64
-#define SP_WARM 48
+#define SP_CHUNK 32
+#define SP_WARM 40
 #define SP_BLK 8
 
 template <class T>
