@@ -68,7 +68,7 @@ def main():
         import torch
         import torch.distributed as dist
         if args.backend == "nccl":
-            torch.cuda.set_device(local)
+            torch.cuda.set_device(0 if args.same_device else local)
         dist.init_process_group(args.backend)
 
     import _ofri
