@@ -113,7 +113,9 @@ int ofri_prof_count(ofri_ctx *ctx, int *count);
 int ofri_prof_read(ofri_ctx *ctx, int idx, float *ms, int *launches, int *sweeps, int *rows, int *cols);
 /* HS as reached through HSOpticalFlowAlgoAdapter.compute (src/HornSchunck.py:35-37,73-105):
  * derivatives, niter sweeps from (U_in, V_in), error (|Un-U_in|_F + |Vn-V_in|_F)/(rows*cols).
- * U_out/V_out must not alias U_in/V_in.  err_host may be NULL (then nothing blocks). */
+ * U_out/V_out must not alias U_in/V_in.  U_in and V_in may both be NULL for a zero initial flow (what the
+ * driver passes after a warp, src/GenericPyramidalOpticalFlow.py:224-225,361-362).  err_host may be NULL (then
+ * nothing blocks). */
 int ofri_hs_compute(ofri_ctx *ctx, const float *frame0, const float *frame1,
                     const float *U_in, const float *V_in, float *U_out, float *V_out,
                     float alpha, int niter, int rows, int cols, double *err_host);

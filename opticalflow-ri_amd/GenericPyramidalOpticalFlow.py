@@ -59,7 +59,8 @@ def shift_warp_device(im, us, vs):
 
 
 def next_level_device(im1, prev_shape, im2, Uacc, Vacc, warping=True, biLinear=True, scale=False):
-    """Level transition (reference updateNextPyramidalLevel, :118-235) on device arrays.  With
+    """Level transition (reference updateNextPyramidalLevel, :118-235) on device arrays.  After a warp the
+    new level starts from a zero flow (:224-225), returned as U = V = None (see _compute).  With
     warping and not biLinear the reference overwrites its first image; here the first returned array is
     that image and the argument is left alone."""
     ctx = im1.ctx
@@ -81,19 +82,21 @@ def next_level_device(im1, prev_shape, im2, Uacc, Vacc, warping=True, biLinear=T
         return im1, im2, ctx.zeros((H, W)), ctx.zeros((H, W)), us, vs
     if not biLinear:
         _say('Warping: Liu-Shen')
-        return shift_warp_device(im1, us, vs), im2, us, vs, ctx.zeros((H, W)), ctx.zeros((H, W))
+        return shift_warp_device(im1, us, vs), im2, us, vs, None, None
     _say('Warping: BiLinear')
     w1, w2 = ctx.empty((H, W)), ctx.empty((H, W))
     _ofri.check(_ofri.lib().ofri_warp_pair(ctx.handle, im1.ptr, im2.ptr, us.ptr, vs.ptr, w1.ptr, w2.ptr, H, W))
-    return w1, w2, us, vs, ctx.zeros((H, W)), ctx.zeros((H, W))
+    return w1, w2, us, vs, None, None
 
 
 def _compute(adapter, im1, im2, U, V):
     """Run one adapter step on device arrays; falls back to the NumPy protocol for foreign adapters."""
+    ctx = im1.ctx
+    if U is None and not getattr(adapter, "accepts_zero_flow_as_none", False):
+        U, V = ctx.zeros(im1.shape), ctx.zeros(im1.shape)
     if hasattr(adapter, "compute_device"):
         Un, Vn, err = adapter.compute_device(im1, im2, U, V, want_error=VERBOSE)
         return Un, Vn, err
-    ctx = im1.ctx
     r = adapter.compute(im1.numpy(), im2.numpy(), U.numpy(), V.numpy())
     return ctx.upload(r[0]), ctx.upload(r[1]), r[2]
 
@@ -146,7 +149,7 @@ def pyramidal_flow_device(im1, im2, FILTER, mainOFlowAlgoAdapter, pyramidalLevel
                     overwritten['im1'] = w1
         else:
             w1, w2 = n1, n2
-            U, V = ctx.zeros(n1.shape), ctx.zeros(n1.shape)
+            U = V = None                         # zero flow (:361-362)
             Uacc = Vacc = None                   # zero so far: the first accumulation adopts U, V instead of adding
         if taps is not None:
             work1, work2 = filter_device(w1, taps), filter_device(w2, taps)
@@ -203,7 +206,7 @@ def updateNextPyramidalLevel(im1IterNext, im1IterPrev, im2IterNext, Uaccum, Vacc
     ctx = _ofri.context()
     r = next_level_device(ctx.upload(im1IterNext), im1IterPrev.shape, ctx.upload(im2IterNext), ctx.upload(Uaccum),
                           ctx.upload(Vaccum), warping, biLinear, scale)
-    out = [a.numpy() for a in r]
+    out = [a.numpy() if a is not None else np.zeros(r[0].shape, np.float32) for a in r]
     if warping and not biLinear and isinstance(im1IterNext, np.ndarray):
         im1IterNext[...] = out[0]            # the reference warps its first argument in place and returns it
         out[0] = im1IterNext

@@ -20,6 +20,8 @@ class HSOpticalFlowAlgoAdapter(object):
         alpha = self.alphas.pop()
         return HS(im1, im2, alpha, self.Niter, U, V)
 
+    accepts_zero_flow_as_none = True     # compute_device takes U = V = None for a zero initial flow
+
     def compute_device(self, im1, im2, U, V, want_error=False):
         """Device-resident form used by the pyramid driver: DeviceArrays in, DeviceArrays out."""
         alpha = self.alphas.pop()
@@ -36,11 +38,13 @@ class HSOpticalFlowAlgoAdapter(object):
 
 
 def hs_device(frame0, frame1, alpha, Niter, U, V, want_error=True):
+    """U = V = None stands for a zero initial flow (no zero planes are made or read on large fields)."""
     ctx = frame0.ctx
     rows, cols = frame0.shape
     Un, Vn = ctx.empty((rows, cols)), ctx.empty((rows, cols))
     err = C.c_double(0.0)
-    _ofri.check(_ofri.lib().ofri_hs_compute(ctx.handle, frame0.ptr, frame1.ptr, U.ptr, V.ptr, Un.ptr, Vn.ptr,
+    _ofri.check(_ofri.lib().ofri_hs_compute(ctx.handle, frame0.ptr, frame1.ptr, U.ptr if U is not None else None,
+                                            V.ptr if V is not None else None, Un.ptr, Vn.ptr,
                                             float(alpha), int(Niter), rows, cols,
                                             C.byref(err) if want_error else None))
     return Un, Vn, (err.value if want_error else None)

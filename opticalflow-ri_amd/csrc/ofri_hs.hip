@@ -299,15 +299,23 @@ extern "C" int ofri_hs_compute(ofri_ctx *ctx, const float *frame0, const float *
                                const float *U_in, const float *V_in, float *U_out, float *V_out,
                                float alpha, int niter, int rows, int cols, double *err_host) {
     OFRI_TRY(ofri_check_ctx(ctx));
-    OFRI_REQUIRE(frame0 && frame1 && U_in && V_in && U_out && V_out, "null pointer");
+    OFRI_REQUIRE(frame0 && frame1 && U_out && V_out, "null pointer");
+    OFRI_REQUIRE((U_in == nullptr) == (V_in == nullptr), "U_in and V_in must both be given or both be null");
     OFRI_REQUIRE(U_out != U_in && V_out != V_in && U_out != V_out, "output must not alias input");
     OFRI_REQUIRE(rows > 0 && cols > 0 && niter >= 0, "bad shape or niter");
     size_t n = (size_t)rows * cols, bytes = n * sizeof(float);
     // HS(im2=frame0, im1=frame1) -> computeDerivatives(im1=frame1, im2=frame0)   (HornSchunck.py:37,73,84)
     const void *q[6] = {frame0, frame1, U_in, V_in, U_out, V_out};
     const int n_stream = hs_stream_share(ctx, q, 6, niter, rows, cols);
+    PoolBuf zu(ctx), zv(ctx);
+    if (!U_in && (n_stream == 0 || err_host)) {       // a zero start that somebody has to read: make it
+        OFRI_TRY(zu.get(bytes)); OFRI_TRY(zv.get(bytes));
+        OFRI_HIP(hipMemsetAsync(zu.p, 0, bytes, ctx->stream));
+        OFRI_HIP(hipMemsetAsync(zv.p, 0, bytes, ctx->stream));
+        U_in = zu.as<float>(); V_in = zv.as<float>();
+    }
     if (n_stream > 0) {
-        // large field: the derivatives go straight into the pipeline's padded planes, no dense copy of them exists
+        // large field: the derivatives (and a zero start) go straight into the pipeline's padded planes
         OFRI_TRY(hs_stream_path(ctx, U_in, V_in, U_out, V_out, nullptr, nullptr, nullptr, frame1, frame0, alpha * alpha, niter,
                                 n_stream, rows, cols));
     } else {

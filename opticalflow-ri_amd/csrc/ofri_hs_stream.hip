@@ -217,7 +217,7 @@ __global__ void k_sl_fill(const float *__restrict__ U, const float *__restrict__
     float gx, gy, gt;
     if (FRAMES) hs_derivs_at(ca, cb, sy, sx, H, W, gx, gy, gt);
     else { gx = ca[s]; gy = cb[s]; gt = cc[s]; }
-    o.U[0][d] = U[s]; o.V[0][d] = V[s]; o.fx[d] = gx; o.fy[d] = gy; o.ft[d] = gt; o.rd[d] = hs_rden(gx, gy, a2);
+    o.U[0][d] = U ? U[s] : 0.f; o.V[0][d] = V ? V[s] : 0.f; o.fx[d] = gx; o.fy[d] = gy; o.ft[d] = gt; o.rd[d] = hs_rden(gx, gy, a2);
 }
 // refresh the mirrored border of a padded plane from its interior
 __global__ void k_sl_repad(float *__restrict__ U, float *__restrict__ V, int P, int H, int W) {
@@ -257,7 +257,7 @@ void ofri_sl_layout(float *base, int H, int W, OfriSlSet *s) {
     s->U[0] = at00(0); s->V[0] = at00(1); s->U[1] = at00(2); s->V[1] = at00(3);
     s->fx = at00(4); s->fy = at00(5); s->ft = at00(6); s->rd = at00(7);
 }
-// U, V dense; coefficients either dense (fx, fy, ft) or, with fx == nullptr, differentiated from the frames
+// U, V dense (both null: zero flow); coefficients either dense (fx, fy, ft) or, with fx == nullptr, differentiated from the frames
 int ofri_sl_fill(ofri_ctx *ctx, const OfriSlSet &s, const float *U, const float *V, const float *fx, const float *fy,
                  const float *ft, const float *first, const float *second, float a2, int H, int W) {
     dim3 b(64, 4), g(ceil_div(s.P, 64), ceil_div(H + 2 * SL_NL, 4));
