@@ -1,5 +1,6 @@
-// Plane set of the Horn-Schunck row-streaming pipeline (ofri_hs_stream.hip): eight planes padded by the
-// pipeline's depth, every pointer at image pixel (0,0), common row pitch P (floats).
+// Plane set of the Horn-Schunck row-streaming pipeline (ofri_hs_stream.hip): eight dense planes in one
+// allocation, in the order U0 V0 U1 V1 fx fy ft rd (the loader relies on V, fy, rd lying one plane after
+// U, fx, ft).  P is the row pitch in floats (= columns).
 #pragma once
 #include "ofri_internal.h"
 
@@ -7,13 +8,14 @@ struct OfriSlSet {
     float *U[2], *V[2];          // ping-pong pairs
     float *fx, *fy, *ft, *rd;    // coefficients and 1/(alpha^2 + fx^2 + fy^2)
     int P;
+    int zero_in;                 // pair 0 stands for a zero flow and holds nothing yet
 };
 
 int ofri_hs_stream_sweeps(void);                       // sweeps per launch
 bool ofri_hs_stream_pays(int H, int W);                // field large enough for the pipeline to win
 size_t ofri_sl_bytes(int H, int W);                    // device bytes of a plane set
 void ofri_sl_layout(float *base, int H, int W, OfriSlSet *s);
-int ofri_sl_fill(ofri_ctx *ctx, const OfriSlSet &s, const float *U, const float *V, const float *fx, const float *fy,
+int ofri_sl_fill(ofri_ctx *ctx, OfriSlSet &s, const float *U, const float *V, const float *fx, const float *fy,
                  const float *ft, const float *first, const float *second, float a2, int H, int W);
-int ofri_sl_sweeps(ofri_ctx *ctx, const OfriSlSet &s, int n, bool to_dense, float *Uout, float *Vout, int H, int W,
+int ofri_sl_sweeps(ofri_ctx *ctx, OfriSlSet &s, int n, bool to_dense, float *Uout, float *Vout, int H, int W,
                    int *cur, int *launches);

@@ -10,10 +10,11 @@
 // unit.  Each input pixel is read once per 12 sweeps (times the strip overlap 128/104), which the tile kernel cannot reach:
 // its halo grows in both directions.
 //
-// The planes are copies padded by 12 mirrored pixels ('mirror' border of the reference: a field extended
-// by reflection stays the reflection of itself under the symmetric stencil), so the pipeline has no border
-// cases and every 16-byte access is aligned.  Arithmetic is the shared sequence of ofri_hs_math.h, so the
-// result is bit-identical to the other Horn-Schunck kernels.
+// Borders ('mirror' of the reference: a field extended by reflection stays the reflection of itself under the
+// symmetric stencil) are the loader's business: rows outside the image are the reflected rows, and in the two
+// outermost strips the lanes beyond the edge gather reflected columns; the stages never see a border.
+// Arithmetic is the shared sequence of ofri_hs_math.h, so the result is bit-identical to the other
+// Horn-Schunck kernels.
 #include "ofri_internal.h"
 #include "ofri_hs_math.h"
 #include "ofri_hs_stream.h"
@@ -42,7 +43,7 @@ __device__ __forceinline__ int sl_refl(int i, int n) {
     return i < n ? i : p - i;
 }
 
-struct SlPlanes { const float *U, *V, *fx, *fy, *ft, *rd; };   // padded planes, pointers at image pixel (0,0)
+struct SlPlanes { const float *U, *V, *fx, *fy, *ft, *rd; };   // dense planes; V, fy, rd one plane after U, fx, ft
 struct SlRow { float u[4], v[4]; };                            // a lane's four pixels of one row
 struct SlCoef { float4 fx, fy, ft, rd; };
 
@@ -110,11 +111,67 @@ __device__ __forceinline__ void sl_stage_step(SlStage &st, float4 (&ring)[SL_NS]
     ++st.rA;
 }
 
-// FULL: all SL_NL sweeps are wanted (no copy-through selects in the inner loop)
+// ---- loader -------------------------------------------------------------------------------------------
+// One lane's four pixels of a row, 'mirror' border: inside the image one 16-byte load; a lane that
+// straddles or lies beyond the left / right edge gathers the reflected columns one by one.
+struct SlCols { int x, x0, x1, x2, x3; bool inside; };    // a lane's first column, its four reflected columns
+template <bool EDGE>
+__device__ __forceinline__ float4 sl_load4(const float *__restrict__ row, const SlCols &c) {
+    if (!EDGE || c.inside) return *reinterpret_cast<const float4 *>(row + c.x);
+    return make_float4(row[c.x0], row[c.x1], row[c.x2], row[c.x3]);
+}
+
+// The loader wavefront's loop.  Lanes 0-31 carry U, fx, ft; lanes 32-63 carry V, fy, 1/den (each one plane
+// after its partner, so the row address is a scalar base plus a per-lane offset).  Rows outside the image are
+// the reflected rows.  EDGE: the strip reaches over the left or right edge of the image.  ZERO: the flow is
+// zero on input and is not read.
+template <bool EDGE, bool ZERO>
+__device__ __forceinline__ void sl_loader(const SlPlanes &in, float4 (&ring)[SL_NS][2][2][32], float4 (&coef)[SL_CR][4][32],
+                                          int tid, int x0, int rho0, int NS, int H, int W) {
+    const int lj = tid & 31, lset = (tid >> 5) & 1;
+    const int lx = x0 + 4 * lj;
+    SlCols cols;                                                       // column reflection does not depend on the row
+    cols.x = lx; cols.inside = lx >= 0 && lx + 3 < W;
+    cols.x0 = sl_refl(lx, W); cols.x1 = sl_refl(lx + 1, W); cols.x2 = sl_refl(lx + 2, W); cols.x3 = sl_refl(lx + 3, W);
+    const long long pl = lset ? (long long)(in.V - in.U) : 0;          // plane stride for the second half-wavefront
+    int lslot = (rho0 + 64 * SL_CR) % SL_CR;                           // slot of the row written next
+    // rows in flight: named registers (an array here ends up in scratch memory, which serialises the prefetch)
+#define SL_LOAD(U_, ROW_)                                                                          \
+    {                                                                                              \
+        const long long o = (long long)sl_refl((ROW_), H) * W;   /* scalar */                      \
+        qa##U_ = ZERO ? make_float4(0.f, 0.f, 0.f, 0.f) : sl_load4<EDGE>(in.U + o + pl, cols);    \
+        qb##U_ = sl_load4<EDGE>(in.fx + o + pl, cols);                                            \
+        qc##U_ = sl_load4<EDGE>(in.ft + o + pl, cols);                                            \
+    }
+    // the compiler must keep the first fill in program order (oldest load = first row consumed), or it has
+    // to wait for every load in flight at the top of each round
+#define SL_Q(U_) float4 qa##U_, qb##U_, qc##U_; SL_LOAD(U_, rho0 + (U_)) asm volatile("" ::: "memory");
+    SL_Q(0) SL_Q(1) SL_Q(2) SL_Q(3) SL_Q(4) SL_Q(5)
+#undef SL_Q
+    static_assert(SL_PF == 6, "the prefetch registers are spelled out for six rows");
+#define SL_STEP(U_)                                                                \
+    {                                                                              \
+        const int rho = rho0 + t0 + (U_);                                          \
+        ring[0][rho & 1][lset][lj] = qa##U_;                                       \
+        coef[lslot][lset][lj] = qb##U_;                                            \
+        coef[lslot][2 + lset][lj] = qc##U_;                                        \
+        lslot = lslot + 1 == SL_CR ? 0 : lslot + 1;                                \
+        SL_LOAD(U_, rho + SL_PF)                                                   \
+        __syncthreads();                                                           \
+    }
+    for (int t0 = 0; t0 < NS; t0 += SL_PF) {
+        SL_STEP(0) SL_STEP(1) SL_STEP(2) SL_STEP(3) SL_STEP(4) SL_STEP(5)
+    }
+#undef SL_STEP
+#undef SL_LOAD
+}
+
+// FULL: all SL_NL sweeps are wanted (no copy-through selects in the inner loop).  All planes are dense with W
+// columns (W % 4 == 0, 16-byte aligned); zero_in: the input flow is zero and in.U, in.V are not read.
 template <bool FULL>
 __global__ void __launch_bounds__(SL_THREADS)
-k_hs_stream(SlPlanes in, float *__restrict__ Uo, float *__restrict__ Vo, long long opitch, int P, int H, int W, int T,
-            int tiles_x, int chunk_rows) {
+k_hs_stream(SlPlanes in, float *__restrict__ Uo, float *__restrict__ Vo, int H, int W, int T, int tiles_x, int chunk_rows,
+            int zero_in) {
     __shared__ float4 ring[SL_NS][2][2][32];      // ring[s]: input rows of stage s.  [row & 1][U|V][lane]
     __shared__ float4 coef[SL_CR][4][32];         // [row slot][fx|fy|ft|1/den][lane]
     const int tid = threadIdx.x;
@@ -130,42 +187,14 @@ k_hs_stream(SlPlanes in, float *__restrict__ Uo, float *__restrict__ Vo, long lo
     // The loader and the stages run separate loops (their registers then overlap instead of adding up);
     // both execute one barrier per step, NS in all.
     if (tid >= SL_NS * 32) {
-        // ---- loader wavefront: lanes 0-31 carry U, fx, ft; lanes 32-63 carry V, fy, 1/den ------------------
-        // V, fy and 1/den lie one plane after U, fx and ft, so a row's address is a scalar base plus a per-lane
-        // byte offset below 2^32: no vector arithmetic per load
-        const int lj = tid & 31, lset = (tid >> 5) & 1;
-        const unsigned lane_bytes = (unsigned)((x0 + SL_NL + 4 * lj) * 4) + (lset ? (unsigned)((in.V - in.U) * 4) : 0u);
-        int lslot = (rho0 + 64 * SL_CR) % SL_CR;               // slot of the row written next
-        // rows in flight: named registers (an array here ends up in scratch memory, which serialises the prefetch)
-#define SL_LOAD(U_, ROW_)                                                                          \
-    {                                                                                              \
-        const int row = min((ROW_), H + SL_NL - 1);                                                \
-        const long long o = (long long)row * P - SL_NL;        /* scalar: start of the padded row */ \
-        qa##U_ = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(in.U + o) + lane_bytes);  \
-        qb##U_ = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(in.fx + o) + lane_bytes); \
-        qc##U_ = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(in.ft + o) + lane_bytes); \
-    }
-        // the compiler must keep the first fill in program order (oldest load = first row consumed), or it has
-        // to wait for every load in flight at the top of each round
-#define SL_Q(U_) float4 qa##U_, qb##U_, qc##U_; SL_LOAD(U_, rho0 + (U_)) asm volatile("" ::: "memory");
-        SL_Q(0) SL_Q(1) SL_Q(2) SL_Q(3) SL_Q(4) SL_Q(5)
-#undef SL_Q
-        static_assert(SL_PF == 6, "the prefetch registers are spelled out for six rows");
-#define SL_STEP(U_)                                                                \
-    {                                                                              \
-        const int rho = rho0 + t0 + (U_);                                          \
-        ring[0][rho & 1][lset][lj] = qa##U_;                                       \
-        coef[lslot][lset][lj] = qb##U_;                                            \
-        coef[lslot][2 + lset][lj] = qc##U_;                                        \
-        lslot = lslot + 1 == SL_CR ? 0 : lslot + 1;                                \
-        SL_LOAD(U_, rho + SL_PF)                                                   \
-        __syncthreads();                                                           \
-    }
-        for (int t0 = 0; t0 < NS; t0 += SL_PF) {
-            SL_STEP(0) SL_STEP(1) SL_STEP(2) SL_STEP(3) SL_STEP(4) SL_STEP(5)
+        const bool edge = x0 < 0 || x0 + SL_RX > W;
+        if (edge) {
+            if (zero_in) sl_loader<true, true>(in, ring, coef, tid, x0, rho0, NS, H, W);
+            else sl_loader<true, false>(in, ring, coef, tid, x0, rho0, NS, H, W);
+        } else {
+            if (zero_in) sl_loader<false, true>(in, ring, coef, tid, x0, rho0, NS, H, W);
+            else sl_loader<false, false>(in, ring, coef, tid, x0, rho0, NS, H, W);
         }
-#undef SL_STEP
-#undef SL_LOAD
     } else {
         // ---- stage half-wavefronts ---------------------------------------------------------------------
         const int stage = tid >> 5, l = tid & 31;
@@ -178,15 +207,15 @@ k_hs_stream(SlPlanes in, float *__restrict__ Uo, float *__restrict__ Vo, long lo
         st.gprev.fx = st.gprev.fy = st.gprev.ft = st.gprev.rd = make_float4(0.f, 0.f, 0.f, 0.f);
         st.rA = rho0 - 2 - 3 * stage;
         st.cslot = (st.rA + 64 * SL_CR) % SL_CR;
-        const bool passA = 2 * stage >= T, passB = 2 * stage + 1 >= T;    // fewer than 16 sweeps asked: copy rows through
+        const bool passA = 2 * stage >= T, passB = 2 * stage + 1 >= T;    // fewer than 12 sweeps asked: copy rows through
         const bool store_lane = l >= SL_NL / 4 && l < 32 - SL_NL / 4 && (x0 + 4 * l) < W;
         const int lane_off = x0 + 4 * l;
         // six steps per round (NS is a multiple): the row registers rotate by renaming instead of moves
 #define SL_STEP(U_)                                                                                                   \
     {                                                                                                                 \
         const int ro = rho0 - SL_LAG + t + (U_);          /* row the last stage finishes at this step */              \
-        sl_stage_step<FULL>(st, ring, coef, stage, l, passA, passB, store_lane, lane_off, Uo + (long long)ro * opitch,  \
-                            Vo + (long long)ro * opitch, ro >= ya && ro < yb);                                        \
+        sl_stage_step<FULL>(st, ring, coef, stage, l, passA, passB, store_lane, lane_off, Uo + (long long)ro * W,     \
+                            Vo + (long long)ro * W, ro >= ya && ro < yb);                                             \
         __syncthreads();                                                                                              \
     }
         for (int t = 0; t < NS; t += SL_PF) { SL_STEP(0) SL_STEP(1) SL_STEP(2) SL_STEP(3) SL_STEP(4) SL_STEP(5) }
@@ -194,83 +223,54 @@ k_hs_stream(SlPlanes in, float *__restrict__ Uo, float *__restrict__ Vo, long lo
     }
 }
 
-// ---- padded copies ------------------------------------------------------------------------------------
-// Fill of a plane set (ofri_hs_stream.h): the image mirrored into a border of SL_NL pixels, 1/(alpha^2 + fx^2 + fy^2)
-// for rd, zeros in the columns between the border and the pitch (the last strip reads them; they only reach
-// pixels that are never stored, but must be finite).  The second U, V pair gets those zeros too.
-// FRAMES: fx, fy, ft are differentiated on the spot from the two frames (ca = first, cb = second image of
-// computeDerivatives); otherwise ca, cb, cc are dense fx, fy, ft.
+// ---- coefficient planes -------------------------------------------------------------------------------
+// fx, fy, ft and 1/(alpha^2 + fx^2 + fy^2) of a plane set.  FRAMES: differentiated on the spot from the two
+// frames (ca = first, cb = second image of computeDerivatives); otherwise ca, cb, cc are fx, fy, ft.
 template <bool FRAMES>
-__global__ void k_sl_fill(const float *__restrict__ U, const float *__restrict__ V, const float *__restrict__ ca,
-                          const float *__restrict__ cb, const float *__restrict__ cc, OfriSlSet o, int H, int W, float a2) {
-    const int P = o.P;
-    const int x = blockIdx.x * blockDim.x + threadIdx.x - SL_NL;
-    const int y = blockIdx.y * blockDim.y + threadIdx.y - SL_NL;
-    if (x >= P - SL_NL || y >= H + SL_NL) return;
-    const long long d = (long long)y * P + x;
-    if (x >= W + SL_NL) {
-        o.U[0][d] = 0.f; o.V[0][d] = 0.f; o.fx[d] = 0.f; o.fy[d] = 0.f; o.ft[d] = 0.f; o.rd[d] = 0.f; o.U[1][d] = 0.f; o.V[1][d] = 0.f;
-        return;
-    }
-    const int sy = sl_refl(y, H), sx = sl_refl(x, W);
-    const size_t s = (size_t)sy * W + sx;
+__global__ void k_sl_coefs(const float *__restrict__ ca, const float *__restrict__ cb, const float *__restrict__ cc, OfriSlSet o,
+                           int H, int W, float a2) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= W || y >= H) return;
+    const size_t s = (size_t)y * W + x;
     float gx, gy, gt;
-    if (FRAMES) hs_derivs_at(ca, cb, sy, sx, H, W, gx, gy, gt);
+    if (FRAMES) hs_derivs_at(ca, cb, y, x, H, W, gx, gy, gt);
     else { gx = ca[s]; gy = cb[s]; gt = cc[s]; }
-    o.U[0][d] = U ? U[s] : 0.f; o.V[0][d] = V ? V[s] : 0.f; o.fx[d] = gx; o.fy[d] = gy; o.ft[d] = gt; o.rd[d] = hs_rden(gx, gy, a2);
-}
-// refresh the mirrored border of a padded plane from its interior
-__global__ void k_sl_repad(float *__restrict__ U, float *__restrict__ V, int P, int H, int W) {
-    // frame pixels enumerated as: top and bottom bands (2*SL_NL rows x (W+2*SL_NL)), then left/right bands (H rows x 2*SL_NL)
-    const long long nband = 2LL * SL_NL * (W + 2 * SL_NL), nside = (long long)H * 2 * SL_NL;
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nband + nside) return;
-    int x, y;
-    if (i < nband) {
-        int row = (int)(i / (W + 2 * SL_NL));
-        x = (int)(i - (long long)row * (W + 2 * SL_NL)) - SL_NL;
-        y = row < SL_NL ? row - SL_NL : H + (row - SL_NL);
-    } else {
-        long long j = i - nband;
-        y = (int)(j / (2 * SL_NL));
-        int c = (int)(j - (long long)y * 2 * SL_NL);
-        x = c < SL_NL ? c - SL_NL : W + (c - SL_NL);
-    }
-    long long d = (long long)y * P + x, s = (long long)sl_refl(y, H) * P + sl_refl(x, W);
-    U[d] = U[s];
-    V[d] = V[s];
+    o.fx[s] = gx; o.fy[s] = gy; o.ft[s] = gt; o.rd[s] = hs_rden(gx, gy, a2);
 }
 
 int ofri_hs_stream_sweeps(void) { return SL_NL; }
-// worth it where the row chunks are long against the pipeline's fill (about 4096 x 3072 pixels and up)
+// worth it where the row chunks are long against the pipeline's fill (2048 x 2048 pixels and up)
 bool ofri_hs_stream_pays(int H, int W) { return (long long)H * W >= 4000000LL && (W & 3) == 0; }
 
-size_t ofri_sl_bytes(int H, int W) {
-    const int tiles_x = ceil_div(W, SL_OX), P = tiles_x * SL_OX + 2 * SL_NL;
-    return 8 * ((size_t)H + 2 * SL_NL) * P * sizeof(float);
-}
+size_t ofri_sl_bytes(int H, int W) { return 8 * (size_t)H * W * sizeof(float); }
 void ofri_sl_layout(float *base, int H, int W, OfriSlSet *s) {
-    const int tiles_x = ceil_div(W, SL_OX);
-    s->P = tiles_x * SL_OX + 2 * SL_NL;                        // multiple of 4; covers the last strip
-    const size_t plane = ((size_t)H + 2 * SL_NL) * s->P;
-    auto at00 = [&](int k) { return base + k * plane + (size_t)SL_NL * s->P + SL_NL; };
-    s->U[0] = at00(0); s->V[0] = at00(1); s->U[1] = at00(2); s->V[1] = at00(3);
-    s->fx = at00(4); s->fy = at00(5); s->ft = at00(6); s->rd = at00(7);
+    const size_t plane = (size_t)H * W;
+    s->U[0] = base; s->V[0] = base + plane; s->U[1] = base + 2 * plane; s->V[1] = base + 3 * plane;
+    s->fx = base + 4 * plane; s->fy = base + 5 * plane; s->ft = base + 6 * plane; s->rd = base + 7 * plane;
+    s->P = W;
+    s->zero_in = 0;
 }
-// U, V dense (both null: zero flow); coefficients either dense (fx, fy, ft) or, with fx == nullptr, differentiated from the frames
-int ofri_sl_fill(ofri_ctx *ctx, const OfriSlSet &s, const float *U, const float *V, const float *fx, const float *fy,
+// U, V dense (both null: zero flow, nothing is copied); coefficients either dense (fx, fy, ft) or, with
+// fx == nullptr, differentiated from the frames
+int ofri_sl_fill(ofri_ctx *ctx, OfriSlSet &s, const float *U, const float *V, const float *fx, const float *fy,
                  const float *ft, const float *first, const float *second, float a2, int H, int W) {
-    dim3 b(64, 4), g(ceil_div(s.P, 64), ceil_div(H + 2 * SL_NL, 4));
-    if (fx) k_sl_fill<false><<<g, b, 0, ctx->stream>>>(U, V, fx, fy, ft, s, H, W, a2);
-    else k_sl_fill<true><<<g, b, 0, ctx->stream>>>(U, V, first, second, nullptr, s, H, W, a2);
+    const size_t bytes = (size_t)H * W * sizeof(float);
+    s.zero_in = U == nullptr;
+    if (U) {
+        OFRI_HIP(hipMemcpyAsync(s.U[0], U, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+        OFRI_HIP(hipMemcpyAsync(s.V[0], V, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    dim3 b(64, 4), g(ceil_div(W, 64), ceil_div(H, 4));
+    if (fx) k_sl_coefs<false><<<g, b, 0, ctx->stream>>>(fx, fy, ft, s, H, W, a2);
+    else k_sl_coefs<true><<<g, b, 0, ctx->stream>>>(first, second, nullptr, s, H, W, a2);
     OFRI_LAUNCH_CHECK();
     return OFRI_OK;
 }
-// n sweeps starting from the pair *cur of the set.  to_dense: the last launch stores into (Uout, Vout), dense
-// with W columns; otherwise the result stays in the set and *cur names its pair (border not refreshed).
-int ofri_sl_sweeps(ofri_ctx *ctx, const OfriSlSet &s, int n, bool to_dense, float *Uout, float *Vout, int H, int W,
+// n sweeps starting from the pair *cur of the set.  to_dense: the last launch stores into (Uout, Vout);
+// otherwise the result stays in the set and *cur names its pair.
+int ofri_sl_sweeps(ofri_ctx *ctx, OfriSlSet &s, int n, bool to_dense, float *Uout, float *Vout, int H, int W,
                    int *cur, int *launches) {
-    const int tiles_x = ceil_div(W, SL_OX), P = s.P;
+    const int tiles_x = ceil_div(W, SL_OX);
     // three workgroups per CU (48 KB of LDS each): as many row chunks as fill the chip once
     const int ncu = ofri_ctx_ncu(ctx);
     int nchunks = 3 * ncu / tiles_x;
@@ -281,18 +281,13 @@ int ofri_sl_sweeps(ofri_ctx *ctx, const OfriSlSet &s, int n, bool to_dense, floa
     int remaining = n, c = *cur;
     for (int k = 0; k < L; ++k) {
         const int T = remaining < SL_NL ? remaining : SL_NL;
-        const bool last = k == L - 1, dense = last && to_dense;
+        const bool dense = k == L - 1 && to_dense;
         SlPlanes in{s.U[c], s.V[c], s.fx, s.fy, s.ft, s.rd};
         float *uo = dense ? Uout : s.U[c ^ 1], *vo = dense ? Vout : s.V[c ^ 1];
-        const long long opitch = dense ? (long long)W : (long long)P;
-        if (T == SL_NL) k_hs_stream<true><<<tiles_x * nchunks, SL_THREADS, 0, ctx->stream>>>(in, uo, vo, opitch, P, H, W, T, tiles_x, chunk_rows);
-        else k_hs_stream<false><<<tiles_x * nchunks, SL_THREADS, 0, ctx->stream>>>(in, uo, vo, opitch, P, H, W, T, tiles_x, chunk_rows);
+        if (T == SL_NL) k_hs_stream<true><<<tiles_x * nchunks, SL_THREADS, 0, ctx->stream>>>(in, uo, vo, H, W, T, tiles_x, chunk_rows, s.zero_in);
+        else k_hs_stream<false><<<tiles_x * nchunks, SL_THREADS, 0, ctx->stream>>>(in, uo, vo, H, W, T, tiles_x, chunk_rows, s.zero_in);
         OFRI_LAUNCH_CHECK();
-        if (!last) {
-            long long m = 2LL * SL_NL * (W + 2 * SL_NL) + (long long)H * 2 * SL_NL;
-            k_sl_repad<<<(int)((m + 255) / 256), 256, 0, ctx->stream>>>(uo, vo, P, H, W);
-            OFRI_LAUNCH_CHECK();
-        }
+        s.zero_in = 0;
         if (!dense) c ^= 1;
         remaining -= T;
     }
