@@ -122,6 +122,80 @@ __global__ void k_resample_x_rows(const float *__restrict__ in, int H, int W_in,
     }
 }
 
+// Both passes in one launch for windows of at most 9 taps: a workgroup makes a 64 x 16 output tile.  It first
+// resamples along x the input rows the tile's y-windows cover (float64 accumulation, rounded to float32 as
+// Pillow stores its intermediate image) into LDS, then along y out of LDS.  Same arithmetic, same bits as
+// the two separate passes; the intermediate image never goes to memory.
+#define RF_TX 64
+#define RF_TY 16
+#define RF_ROWS 48                       // input rows a tile may need (16 outputs at 2:1 need 38)
+#define RF_SEG 160                       // input columns a tile may need (64 outputs at 2:1 need 137)
+__global__ void __launch_bounds__(256)
+k_resize_fused(const float *__restrict__ in, int H_in, int W_in, float *__restrict__ out, int H_out, int W_out,
+               ResampleTable tx, ResampleTable ty) {
+    __shared__ float hrow[RF_ROWS][RF_TX];
+    __shared__ float seg[2][4][RF_SEG];                                // input row segments, double buffered
+    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;           // 64 x 4: one wavefront per input row
+    const int xb = blockIdx.x * RF_TX, x = xb + lx, y0 = blockIdx.y * RF_TY;
+    const int ylast = min(y0 + RF_TY, H_out) - 1, xlast = min(xb + RF_TX, W_out) - 1;
+    const int rlo = ty.bounds[2 * y0], rhi = ty.bounds[2 * ylast] + ty.bounds[2 * ylast + 1];   // uniform
+    const int xlo = tx.bounds[2 * xb], span = min(tx.bounds[2 * xlast] + tx.bounds[2 * xlast + 1] - xlo, RF_SEG);
+    double w[9];
+    int off[9];
+    {
+        const int xc = min(x, W_out - 1);
+        const int lo = tx.bounds[2 * xc], cnt = tx.bounds[2 * xc + 1];
+        const double *k = tx.w + xc;
+        const size_t ks = (size_t)tx.n_out;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            off[i] = min(lo + (i < cnt ? i : (cnt > 0 ? cnt - 1 : 0)) - xlo, RF_SEG - 1);
+            w[i] = i < cnt ? k[i * ks] : 0.0;
+        }
+    }
+    int buf = 0;
+    for (int r0 = rlo; r0 < rhi; r0 += 4, buf ^= 1) {
+        const int r = r0 + ly;
+        const bool live = r < rhi && r - rlo < RF_ROWS;                 // second test: never past the LDS rows
+        if (live) {
+            const float *row = in + (size_t)r * W_in + xlo;
+            for (int i = lx; i < span; i += 64) seg[buf][ly][i] = row[i];
+        }
+        __syncthreads();
+        if (live) {
+            double ss = 0.0;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) ss = __dadd_rn(ss, __dmul_rn((double)seg[buf][ly][off[i]], w[i]));
+            hrow[r - rlo][lx] = (float)ss;
+        }
+    }
+    __syncthreads();
+    if (x >= W_out) return;
+#pragma unroll
+    for (int j = 0; j < RF_TY / 4; ++j) {
+        const int y = y0 + ly + 4 * j;
+        if (y >= H_out) break;
+        const int lo = ty.bounds[2 * y], cnt = ty.bounds[2 * y + 1];
+        const double *k = ty.w + y;
+        const size_t ks = (size_t)ty.n_out;
+        double ss = 0.0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const int ii = i < cnt ? i : (cnt > 0 ? cnt - 1 : 0);
+            const double wi = i < cnt ? k[i * ks] : 0.0;
+            ss = __dadd_rn(ss, __dmul_rn((double)hrow[lo + ii - rlo][lx], wi));
+        }
+        out[(size_t)y * W_out + x] = (float)ss;
+    }
+}
+// a tile's windows must fit the LDS rows / columns: true for every tile when the scale and support are modest
+static bool resize_fused_fits(int n_in, int n_out, const ResampleTable &t, int filter, int tile, int room) {
+    if (t.ksize > 9) return false;
+    const double scale = (double)n_in / (double)n_out, fs = scale < 1.0 ? 1.0 : scale;
+    const double sup = (filter == 0 ? 2.0 : 1.0) * fs;
+    return (tile - 1) * scale + 2.0 * sup + 3.0 <= (double)room;
+}
+
 template <int AXIS>
 static void resample_launch(ofri_ctx *ctx, dim3 g, dim3 b, const float *in, int H_in, int W_in, float *out, int H_out,
                             int W_out, const ResampleTable &t) {
@@ -148,6 +222,17 @@ static int resize_generic(ofri_ctx *ctx, const float *src, int rows_in, int cols
     dim3 b(64, 4);
     const float *cur = src;
     PoolBuf tmp(ctx);
+    if (need_h && need_v) {
+        ResampleTable th, tv;
+        OFRI_TRY(get_resample_table(ctx, cols_in, cols_out, filter, &th));
+        OFRI_TRY(get_resample_table(ctx, rows_in, rows_out, filter, &tv));
+        if (resize_fused_fits(cols_in, cols_out, th, filter, RF_TX, RF_SEG) && resize_fused_fits(rows_in, rows_out, tv, filter, RF_TY, RF_ROWS)) {
+            dim3 g(ceil_div(cols_out, RF_TX), ceil_div(rows_out, RF_TY));
+            k_resize_fused<<<g, 256, 0, ctx->stream>>>(src, rows_in, cols_in, dst, rows_out, cols_out, th, tv);
+            OFRI_LAUNCH_CHECK();
+            return OFRI_OK;
+        }
+    }
     if (need_h) {
         ResampleTable t;
         OFRI_TRY(get_resample_table(ctx, cols_in, cols_out, filter, &t));
