@@ -369,7 +369,8 @@ k_spline_bwd(const double *__restrict__ DP, double *__restrict__ M, int n, int L
     // unknown i lives at array index i+1; the last unknown equals its forward value exactly
     double next = dl[(size_t)(we + 1) * L];
     if (we < e) ml[(size_t)(we + 1) * L] = next;
-    double m_first = 0.0, m_second = 0.0;      // unknowns s and s+1 (closing relation of chunk 0)
+    // unknowns s and s+1 (closing relation of chunk 0); with only two unknowns the second is the start value
+    double m_first = 0.0, m_second = (we == s + 1) ? next : 0.0;
     double m_last = next, m_last2 = 0.0;       // unknowns m-1 and m-2 (last chunk)
     for (int i0 = we - 1; i0 >= s; i0 -= SP_BLK) {
         double dv[SP_BLK], cv[SP_BLK];

@@ -246,6 +246,21 @@ def test_shift_warp_driver_vs_reference(ctx, pair):
     assert np.count_nonzero(a0 != pair[0][:256, :256]) > 10000        # the caller's image was overwritten
 
 
+@pytest.mark.parametrize("shape_in,shape_out", [((4, 4), (9, 7)), ((5, 6), (10, 12)), ((4, 70), (8, 141)), ((33, 35), (67, 70)),
+                                                ((66, 67), (133, 131)), ((130, 40), (260, 83)), ((64, 64), (300, 100))])
+def test_spline_upsample_small_and_ragged(ctx, shape_in, shape_out):
+    """FITPACK's interpolating spline (RectBivariateSpline, reference :152-162) on sizes around the solver's
+    chunk boundaries, the smallest legal grid, and factors other than 2."""
+    import GenericPyramidalOpticalFlow as G
+    from oracle import pyramid
+    rng = np.random.default_rng(shape_in[0] * 100 + shape_in[1])
+    F = rng.standard_normal(shape_in).astype(np.float32).cumsum(0).cumsum(1).astype(np.float32) * 0.1
+    want = pyramid.spline_upsample_lib(F, shape_out)
+    got = G.spline_upsample_device(ctx.upload(F), shape_out).numpy()
+    assert got.shape == tuple(shape_out)
+    assert np.abs(got - want).max() <= 2e-6 * max(1.0, np.abs(want).max())
+
+
 # ------------------------------------------------------------------------------ whole driver
 def _driver_case(name, U, V):
     d = load_gold("driver")
