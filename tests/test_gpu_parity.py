@@ -520,3 +520,52 @@ def test_lk_asymmetric_windows_and_driver(ctx, pair):
     r = flow_rel(U, V, Ur, Vr)
     print("driver dense LK rel L2 vs oracle", r)
     assert r < 1e-4
+
+
+# ------------------------------------------------------------------------------ C ABI behaviour
+def test_abi_rejects_bad_arguments_and_stays_usable(ctx):
+    """Bad calls return a negative code with a message (no exception crosses the ABI, no kernel runs) and
+    leave the context usable."""
+    import ctypes as C
+    import _ofri
+    lib = _ofri.lib()
+    a = ctx.upload(np.ones((16, 16), np.float32))
+    b = ctx.empty((16, 16)); c = ctx.empty((16, 16))
+    taps = np.array([0.25, 0.5, 0.25], np.float32)
+    even = np.array([0.5, 0.5], np.float32)
+    err = C.c_double()
+    cases = [
+        lib.ofri_gauss_sep(ctx.handle, None, b.ptr, 16, 16, taps.ctypes.data, 3),                        # null source
+        lib.ofri_gauss_sep(ctx.handle, a.ptr, b.ptr, 0, 16, taps.ctypes.data, 3),                        # empty shape
+        lib.ofri_gauss_sep(ctx.handle, a.ptr, b.ptr, 16, 16, even.ctypes.data, 2),                       # even tap count
+        lib.ofri_hs_compute(ctx.handle, a.ptr, a.ptr, a.ptr, a.ptr, a.ptr, b.ptr, 1.0, 3, 16, 16, None),  # output aliases input
+        lib.ofri_hs_compute(ctx.handle, a.ptr, a.ptr, a.ptr, None, b.ptr, c.ptr, 1.0, 3, 16, 16, None),   # only one of U, V null
+        lib.ofri_hs_compute(ctx.handle, a.ptr, a.ptr, None, None, b.ptr, c.ptr, 1.0, -1, 16, 16, None),   # negative sweeps
+        lib.ofri_hs_iterate(ctx.handle, b.ptr, c.ptr, a.ptr, a.ptr, None, 1.0, 3, 16, 16),               # null coefficient plane
+        lib.ofri_spline_upsample(ctx.handle, a.ptr, 3, 16, b.ptr, 6, 32, 1.0),                           # fewer than 4 knots
+        lib.ofri_resize_bicubic(ctx.handle, a.ptr, 16, 16, a.ptr, 8, 8),                                 # in place
+        lib.ofri_hs_set_fuse(ctx.handle, 1000),
+        lib.ofri_hs_compute(None, a.ptr, a.ptr, None, None, b.ptr, c.ptr, 1.0, 3, 16, 16, None),         # null context
+    ]
+    assert all(rc < 0 for rc in cases), cases
+    assert lib.ofri_last_error()                                   # the last failure left its message
+    # still works, and a zero start given as NULL equals one given as planes of zeros
+    z = ctx.zeros((16, 16))
+    assert lib.ofri_hs_compute(ctx.handle, a.ptr, a.ptr, None, None, b.ptr, c.ptr, 2.0, 5, 16, 16, C.byref(err)) == 0
+    d, e = ctx.empty((16, 16)), ctx.empty((16, 16))
+    assert lib.ofri_hs_compute(ctx.handle, a.ptr, a.ptr, z.ptr, z.ptr, d.ptr, e.ptr, 2.0, 5, 16, 16, None) == 0
+    np.testing.assert_array_equal(b.numpy(), d.numpy()); np.testing.assert_array_equal(c.numpy(), e.numpy())
+
+
+def test_hs_zero_start_as_null_on_streaming_sizes(ctx):
+    """On fields that take the row-streaming pipeline a NULL start skips the zero planes; same bits."""
+    from HornSchunck import hs_device
+    from piv_synth import synth_piv
+    a, b = synth_piv(2048, 2048, seed=3)
+    A, B = ctx.upload(a.astype(np.float32)), ctx.upload(b.astype(np.float32))
+    z = ctx.zeros(A.shape)
+    for nit in (30, 24, 7):                                        # pipeline + tile rest, pipeline only, tile only
+        U0, V0, e0 = hs_device(A, B, 21.0, nit, None, None, True)
+        U1, V1, e1 = hs_device(A, B, 21.0, nit, z, z, True)
+        np.testing.assert_array_equal(U0.numpy(), U1.numpy()); np.testing.assert_array_equal(V0.numpy(), V1.numpy())
+        assert e0 == e1 and np.isfinite(U0.numpy()).all()
