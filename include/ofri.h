@@ -99,8 +99,14 @@ int ofri_gauss_taps(double sigma, int ksize, float *taps_host);
 int ofri_hs_derivs(ofri_ctx *ctx, const float *first, const float *second,
                    float *fx, float *fy, float *ft, int rows, int cols);
 /* HS_helper + HS_helper2 (src/HornSchunck.py:52-71): niter Jacobi sweeps, result left in U, V.
- * Several sweeps are fused per launch (temporal blocking); ofri_hs_set_fuse(ctx, t) pins the number
- * of sweeps per launch (t = 0: automatic, t = 1: one launch per sweep). */
+ * Several sweeps are fused per launch (temporal blocking).  ofri_hs_set_fuse(ctx, t) selects how:
+ *   t = 0   automatic: row-streaming pipeline (12 sweeps per launch) on fields of 2048 x 2048 pixels and
+ *           more, tile kernel (up to 8 per launch) for the rest and for smaller fields;
+ *   t = 1   one launch per sweep;  t = 2..8  tile kernel with at most t sweeps per launch;
+ *   t = 16  row-streaming pipeline for every sweep, any field size;
+ *   t = -1  exact mode: one launch per sweep with scipy's float64 tap accumulation and NumPy's unfused
+ *           float32 element operations, bit-identical to the reference.
+ * All settings but -1 give the same bits as each other. */
 int ofri_hs_iterate(ofri_ctx *ctx, float *U, float *V, const float *fx, const float *fy,
                     const float *ft, float alpha, int niter, int rows, int cols);
 int ofri_hs_set_fuse(ofri_ctx *ctx, int sweeps_per_launch);

@@ -198,8 +198,8 @@ static int hs_stream_share(ofri_ctx *ctx, const void *const *ptrs, int nptrs, in
 }
 
 // n_stream sweeps through the pipeline, the remaining niter - n_stream (fewer than 12) through the tile kernel
-// reading the pipeline's padded planes.  Coefficients: dense fx, fy, ft, or (fx == nullptr) differentiated from
-// the frames straight into the padded planes.  The padding pass is not part of the timing records.
+// reading the pipeline's plane set.  Coefficients: dense fx, fy, ft, or (fx == nullptr) differentiated from
+// the frames straight into the set.  Filling the set is not part of the timing records.
 static int hs_stream_path(ofri_ctx *ctx, const float *Uin, const float *Vin, float *Uout, float *Vout, const float *fx,
                           const float *fy, const float *ft, const float *first, const float *second, float a2, int niter,
                           int n_stream, int rows, int cols) {
@@ -315,7 +315,7 @@ extern "C" int ofri_hs_compute(ofri_ctx *ctx, const float *frame0, const float *
         U_in = zu.as<float>(); V_in = zv.as<float>();
     }
     if (n_stream > 0) {
-        // large field: the derivatives (and a zero start) go straight into the pipeline's padded planes
+        // large field: the derivatives go straight into the pipeline's plane set; a zero start is not materialised
         OFRI_TRY(hs_stream_path(ctx, U_in, V_in, U_out, V_out, nullptr, nullptr, nullptr, frame1, frame0, alpha * alpha, niter,
                                 n_stream, rows, cols));
     } else {
