@@ -105,6 +105,54 @@ k_gauss_fused(const float *__restrict__ in, float *__restrict__ out, int H, int 
     }
 }
 
+// Rows+columns in registers for widths that are multiples of 4 (16-byte aligned planes): a thread owns 4
+// adjacent columns of GV_R consecutive rows, row-filters the GV_R + 2h source rows it needs (one 16-byte load
+// plus 2h border-mapped scalars each) and column-filters out of registers.  Same operation order per output
+// as the other kernels.
+#define GV_R 8
+template <int K>
+__global__ void __launch_bounds__(256)
+k_gauss_vec4(const float *__restrict__ in, float *__restrict__ out, int H, int W, GaussTaps taps) {
+    constexpr int h = K / 2;
+    const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int y0 = (blockIdx.y * blockDim.y + threadIdx.y) * GV_R;
+    if (x0 >= W || y0 >= H) return;
+    int xl[h > 0 ? h : 1], xr[h > 0 ? h : 1];
+#pragma unroll
+    for (int i = 0; i < h; ++i) { xl[i] = gauss_idx(x0 - h + i, W, h); xr[i] = gauss_idx(x0 + 4 + i, W, h); }
+    float rf[GV_R + 2 * h][4];
+#pragma unroll
+    for (int i = 0; i < GV_R + 2 * h; ++i) {
+        const int y = clampi(gauss_idx(y0 - h + i, H, h), 0, H - 1);     // rows past the last consumed one: any valid row
+        const float *row = in + (size_t)y * W;
+        float v[4 + 2 * h];
+        const float4 c = *reinterpret_cast<const float4 *>(row + x0);
+        v[h] = c.x; v[h + 1] = c.y; v[h + 2] = c.z; v[h + 3] = c.w;
+#pragma unroll
+        for (int q = 0; q < h; ++q) { v[q] = row[xl[q]]; v[h + 4 + q] = row[xr[q]]; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < K; ++j) acc = __fadd_rn(acc, __fmul_rn(v[k + 2 * h - j], taps.k[j]));
+            rf[i][k] = acc;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < GV_R; ++r) {
+        if (y0 + r >= H) break;
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < K; ++j) acc = __fadd_rn(acc, __fmul_rn(rf[r + 2 * h - j][k], taps.k[j]));
+            o[k] = acc;
+        }
+        *reinterpret_cast<float4 *>(out + (size_t)(y0 + r) * W + x0) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
 extern "C" int ofri_gauss_sep(ofri_ctx *ctx, const float *src, float *dst, int rows, int cols, const float *taps_host, int ntaps) {
     OFRI_TRY(ofri_check_ctx(ctx));
     OFRI_REQUIRE(src && dst && taps_host, "null pointer");
@@ -121,6 +169,16 @@ extern "C" int ofri_gauss_sep(ofri_ctx *ctx, const float *src, float *dst, int r
     if (!fused || src == dst) OFRI_TRY(tmp.get(bytes));
     if (fused) {
         float *o = (src == dst) ? tmp.as<float>() : dst;
+        const bool vec = (cols & 3) == 0 && ((((size_t)src | (size_t)o) & 15) == 0);
+        if (vec) {
+            dim3 bv(64, 4), gv(ceil_div(cols, 256), ceil_div(rows, 4 * GV_R));
+            if (ntaps == 3) k_gauss_vec4<3><<<gv, bv, 0, ctx->stream>>>(src, o, rows, cols, t);
+            else if (ntaps == 5) k_gauss_vec4<5><<<gv, bv, 0, ctx->stream>>>(src, o, rows, cols, t);
+            else k_gauss_vec4<7><<<gv, bv, 0, ctx->stream>>>(src, o, rows, cols, t);
+            OFRI_LAUNCH_CHECK();
+            if (o != dst) OFRI_HIP(hipMemcpyAsync(dst, o, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+            return OFRI_OK;
+        }
         dim3 b(64, 4), g(ceil_div(cols, GT_X), ceil_div(rows, GT_Y));
         if (ntaps == 3) k_gauss_fused<3><<<g, b, 0, ctx->stream>>>(src, o, rows, cols, t);
         else if (ntaps == 5) k_gauss_fused<5><<<g, b, 0, ctx->stream>>>(src, o, rows, cols, t);

@@ -270,6 +270,11 @@ int ofri_sl_fill(ofri_ctx *ctx, OfriSlSet &s, const float *U, const float *V, co
 // otherwise the result stays in the set and *cur names its pair.
 int ofri_sl_sweeps(ofri_ctx *ctx, OfriSlSet &s, int n, bool to_dense, float *Uout, float *Vout, int H, int W,
                    int *cur, int *launches) {
+    // the loader addresses V, fy, rd as U, fx, ft plus one common plane stride
+    OFRI_REQUIRE(s.V[0] - s.U[0] == s.V[1] - s.U[1] && s.fy - s.fx == s.V[0] - s.U[0] && s.rd - s.ft == s.V[0] - s.U[0] &&
+                     s.V[0] > s.U[0] && (s.V[0] - s.U[0]) < (1LL << 29),
+                 "plane set is not laid out as U V U V fx fy ft rd");
+    OFRI_REQUIRE((W & 3) == 0 && H >= 1 && W >= 4, "row-streaming pipeline needs a width that is a multiple of 4");
     const int tiles_x = ceil_div(W, SL_OX);
     // three workgroups per CU (48 KB of LDS each): as many row chunks as fill the chip once
     const int ncu = ofri_ctx_ncu(ctx);
