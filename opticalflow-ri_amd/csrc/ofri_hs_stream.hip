@@ -94,8 +94,16 @@ __device__ __forceinline__ void sl_stage_step(SlStage &st, float4 (&ring)[SL_NS]
     SlRow nw;
     nw.u[0] = nu4.x; nw.u[1] = nu4.y; nw.u[2] = nu4.z; nw.u[3] = nu4.w;
     nw.v[0] = nv4.x; nw.v[1] = nv4.y; nw.v[2] = nv4.z; nw.v[3] = nv4.w;
-    const SlRow mid2 = sl_sweep<FULL>(st.in0, st.in1, nw, g, passA);                  // row rA of the first sweep
-    const SlRow out = sl_sweep<FULL>(st.mid0, st.mid1, mid2, st.gprev, passB);        // row rA-1 of the second sweep
+    SlRow mid2, out;
+    if (!FULL && __builtin_amdgcn_ballot_w64(!(passA && passB)) == 0) {
+        // neither stage of this wavefront has a sweep to do (fewer sweeps asked than the pipeline is deep):
+        // hand the rows on untouched
+        mid2 = st.in1;
+        out = st.mid1;
+    } else {
+        mid2 = sl_sweep<FULL>(st.in0, st.in1, nw, g, passA);                   // row rA of the first sweep
+        out = sl_sweep<FULL>(st.mid0, st.mid1, mid2, st.gprev, passB);         // row rA-1 of the second sweep
+    }
     const int rB = st.rA - 1;
     if (stage < SL_NS - 1) {
         ring[stage + 1][rB & 1][0][l] = make_float4(out.u[0], out.u[1], out.u[2], out.u[3]);
