@@ -118,6 +118,82 @@ def check(rc):
         raise OfriError("libofri_hip error %d: %s" % (rc, msg.decode("utf-8", "replace") if msg else "?"))
 
 
+class _PinnedLease(object):
+    """A block of pinned host memory that backs one ndarray handed to the caller.  The ndarray keeps
+    this object alive through its .base chain; when the last view dies the block goes back to the pool."""
+
+    __slots__ = ("ptr", "cap", "nbytes", "__weakref__")
+
+    def __init__(self, ptr, cap, nbytes):
+        self.ptr, self.cap, self.nbytes = ptr, cap, nbytes
+
+    @property
+    def __array_interface__(self):
+        return {"shape": (self.nbytes,), "typestr": "|u1", "data": (self.ptr, False), "version": 3}
+
+    def __del__(self):
+        try:
+            _pinned.give_back(self.ptr, self.cap)
+        except Exception:
+            pass
+
+
+class _PinnedPool(object):
+    """Process-wide free lists of pinned host blocks for results copied back from the GPU.  A copy into
+    pinned memory runs at the link rate (about 57 GB/s on MI355X hosts against 11 GB/s into a freshly
+    allocated pageable array), and frame loops ask for the same sizes again and again."""
+
+    MIN_BYTES = 1 << 20            # smaller results take the ordinary pageable path
+    GRAIN = 1 << 21
+    MAX_IDLE_BYTES = 2 << 30       # idle blocks kept for reuse; the rest goes back to the driver
+    MAX_LIVE_BYTES = 16 << 30      # results the caller still holds; beyond this they are pageable again
+
+    def __init__(self):
+        self._free = {}
+        self._idle = 0
+        self._live = 0
+        self._lock = threading.Lock()
+
+    def lease(self, nbytes):
+        """A block of at least nbytes, or None when the caller already holds MAX_LIVE_BYTES of results
+        (a loop that keeps every flow field must not pin the whole host memory)."""
+        cap = (nbytes + self.GRAIN - 1) // self.GRAIN * self.GRAIN
+        with self._lock:
+            if self._live + cap > self.MAX_LIVE_BYTES:
+                return None
+            self._live += cap
+            lst = self._free.get(cap)
+            if lst:
+                self._idle -= cap
+                return _PinnedLease(lst.pop(), cap, nbytes)
+        p = _vp()
+        if lib().ofri_host_alloc(cap, C.byref(p)) != 0:
+            with self._lock:
+                self._live -= cap
+            return None
+        return _PinnedLease(p.value, cap, nbytes)
+
+    def give_back(self, ptr, cap):
+        with self._lock:
+            self._live -= cap
+            if self._idle + cap <= self.MAX_IDLE_BYTES:
+                self._free.setdefault(cap, []).append(ptr)
+                self._idle += cap
+                return
+        lib().ofri_host_free(_vp(ptr))
+
+    def trim(self):
+        with self._lock:
+            blocks = [p for lst in self._free.values() for p in lst]
+            self._free.clear()
+            self._idle = 0
+        for p in blocks:
+            lib().ofri_host_free(_vp(p))
+
+
+_pinned = _PinnedPool()
+
+
 class Context(object):
     """One GPU, one stream, one memory pool."""
 
@@ -170,6 +246,15 @@ class Context(object):
         return a
 
     def upload(self, arr, dtype=np.float32):
+        src = np.asarray(arr)
+        if np.dtype(dtype) == np.float32 and src.dtype in (np.uint8, np.uint16) and src.size >= (1 << 16):
+            # camera frames: send the raw samples and widen on the GPU (exact for both types) instead of
+            # converting 4x / 2x the bytes on one host core first
+            raw = self.upload(src, src.dtype)
+            a = DeviceArray(self, src.shape, np.float32)
+            widen = lib().ofri_u8_to_f32 if src.dtype == np.uint8 else lib().ofri_u16_to_f32
+            check(widen(self._h, raw.ptr, a.ptr, src.size))
+            return a
         arr = np.ascontiguousarray(arr, dtype=dtype)
         a = DeviceArray(self, arr.shape, dtype)
         check(lib().ofri_upload(self._h, a.ptr, arr.ctypes.data, arr.nbytes))
@@ -217,6 +302,13 @@ class DeviceArray(object):
         return int(np.prod(self.shape))
 
     def numpy(self):
+        """Copy to the host.  Large results land in pooled pinned memory that the returned ndarray owns
+        (an ordinary writable array to the caller); small ones in a plain np.empty."""
+        lease = _pinned.lease(self.nbytes) if self.nbytes >= _PinnedPool.MIN_BYTES else None
+        if lease is not None:
+            check(lib().ofri_download_async(self.ctx.handle, _vp(lease.ptr), self.ptr, self.nbytes))
+            self.ctx.sync()
+            return np.asarray(lease).view(self.dtype).reshape(self.shape)
         out = np.empty(self.shape, self.dtype)
         if self.nbytes:
             check(lib().ofri_download(self.ctx.handle, out.ctypes.data, self.ptr, self.nbytes))

@@ -1,0 +1,90 @@
+"""Host <-> device copies of the Python host layer: results copied back into pooled pinned memory and
+camera frames widened on the GPU must be indistinguishable, bit for bit, from the plain pageable copies."""
+import ctypes as C
+import gc
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def pageable_download(ctx, d):
+    import _ofri
+    out = np.empty(d.shape, d.dtype)
+    _ofri.check(_ofri.lib().ofri_download(ctx.handle, out.ctypes.data, d.ptr, d.nbytes))
+    return out
+
+
+def test_large_results_come_back_in_pinned_memory_bit_identical():
+    import _ofri
+    ctx = _ofri.context(0)
+    rng = np.random.default_rng(3)
+    src = rng.standard_normal((1536, 1024)).astype(np.float32)      # 6 MB: above the pinned threshold
+    src.ravel()[:4] = [np.nan, np.inf, -0.0, np.float32(1e-42)]      # payload bits must survive
+    d = ctx.upload(src)
+    a = d.numpy()
+    assert isinstance(a.base, np.ndarray) and a.flags.writeable and a.flags.c_contiguous
+    ref = pageable_download(ctx, d)
+    assert a.tobytes() == ref.tobytes() == src.tobytes()
+    # the array behaves like any other: views keep it alive, writes stay local
+    v = a[100:200, 5:50]
+    a[...] = 7.0
+    del a
+    gc.collect()
+    assert np.all(v == 7.0)
+    assert d.numpy().tobytes() == src.tobytes()
+    # the block is reused once the last view is gone
+    del v
+    gc.collect()
+    idle = _ofri._pinned._idle
+    assert idle >= src.nbytes
+    b = d.numpy()
+    assert _ofri._pinned._idle == idle - (src.nbytes + _ofri._PinnedPool.GRAIN - 1) // _ofri._PinnedPool.GRAIN * _ofri._PinnedPool.GRAIN
+    assert b.tobytes() == src.tobytes()
+
+
+def test_small_and_float64_results():
+    import _ofri
+    ctx = _ofri.context(0)
+    small = np.arange(12, dtype=np.float32).reshape(3, 4)
+    assert np.array_equal(ctx.upload(small).numpy(), small)
+    big64 = np.random.default_rng(0).standard_normal((600, 700))
+    d = ctx.upload(big64, np.float64)
+    assert d.numpy().dtype == np.float64 and d.numpy().tobytes() == big64.tobytes()
+
+
+def test_results_beyond_the_live_cap_fall_back_to_pageable(monkeypatch):
+    import _ofri
+    ctx = _ofri.context(0)
+    src = np.random.default_rng(1).random((1024, 1024)).astype(np.float32)
+    d = ctx.upload(src)
+    monkeypatch.setattr(_ofri._pinned, "MAX_LIVE_BYTES", 0)
+    a = d.numpy()
+    assert a.base is None and a.tobytes() == src.tobytes()
+
+
+@pytest.mark.parametrize("dtype, top", [(np.uint8, 255), (np.uint16, 65535)])
+def test_camera_frames_are_widened_on_the_gpu_exactly(dtype, top):
+    import _ofri
+    ctx = _ofri.context(0)
+    rng = np.random.default_rng(5)
+    f = rng.integers(0, top + 1, size=(513, 771), dtype=dtype)
+    f.ravel()[:2] = [0, top]
+    got = ctx.upload(f).numpy()
+    assert got.dtype == np.float32 and got.tobytes() == f.astype(np.float32).tobytes()
+    # non-contiguous input (a crop of a larger frame) goes the same way
+    crop = f[3:500, 7:700]
+    assert ctx.upload(crop).numpy().tobytes() == crop.astype(np.float32).tobytes()
+
+
+def test_driver_accepts_uint8_frames_like_float32_frames(pair):
+    from GenericPyramidalOpticalFlow import genericPyramidalOpticalFlow
+    from HornSchunck import HSOpticalFlowAlgoAdapter
+    a, b = pair
+    a8, b8 = np.clip(a, 0, 255).astype(np.uint8), np.clip(b, 0, 255).astype(np.uint8)
+    big = np.tile(a8, (2, 2)), np.tile(b8, (2, 2))      # large enough for the raw-frame path
+    U1, V1 = genericPyramidalOpticalFlow(big[0], big[1], 3.4, HSOpticalFlowAlgoAdapter([21, 45], 20), 2, 1, None)
+    U2, V2 = genericPyramidalOpticalFlow(big[0].astype(np.float32), big[1].astype(np.float32), 3.4,
+                                         HSOpticalFlowAlgoAdapter([21, 45], 20), 2, 1, None)
+    assert U1.tobytes() == U2.tobytes() and V1.tobytes() == V2.tobytes()
