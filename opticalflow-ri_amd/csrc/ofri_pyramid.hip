@@ -1,4 +1,4 @@
-// Pyramid glue: Pillow-compatible resampling, interpolating-spline flow upsampling, bilinear warp.
+// Pyramid glue: Pillow-compatible resampling and the bilinear warps (spline flow upsampling: ofri_spline.hip).
 // Reference behaviour: src/GenericPyramidalOpticalFlow.py:67-235.
 #include "ofri_internal.h"
 #include <cmath>
@@ -260,233 +260,6 @@ extern "C" int ofri_resize_bicubic(ofri_ctx *ctx, const float *src, int rows_in,
 extern "C" int ofri_resize_bilinear(ofri_ctx *ctx, const float *src, int rows_in, int cols_in,
                                     float *dst, int rows_out, int cols_out) {
     return resize_generic(ctx, src, rows_in, cols_in, dst, rows_out, cols_out, 1);
-}
-
-// ---------------------------------------------------------------------------------------------
-// Interpolating bicubic spline (FITPACK k = 3, s = 0 == not-a-knot cubic spline per axis).
-// Per line: second derivatives M (knot units) from the tridiagonal system
-//   M[i-1] + 4 M[i] + M[i+1] = 6 (y[i-1] - 2 y[i] + y[i+1]),  i = 1..n-2,
-// closed by M[0] = 2M[1]-M[2], M[n-1] = 2M[n-2]-M[n-3]; forward-elimination factors depend on n only
-// and come from a host table.  Value at knot k + theta:
-//   (1-theta) y[k] + theta y[k+1] + (((1-theta)^3-(1-theta)) M[k] + (theta^3-theta) M[k+1]) / 6.
-struct SplineSolveTable { const double *cp; const double *inv; };   // device: cp[m], 1/den[m], m = n-2
-
-static int get_spline_solve(ofri_ctx *ctx, int n, SplineSolveTable *t) {
-    std::string key = "sp_" + std::to_string(n);
-    void *pc = ofri_find_table(ctx, key + "c"), *pi = ofri_find_table(ctx, key + "i");
-    if (!pc || !pi) {
-        int m = n - 2;
-        std::vector<double> cp(m), inv(m);
-        // rows: [6 0] first, [1 4 1] interior, [0 6] last
-        double dia0 = 6.0, sup0 = 0.0;
-        cp[0] = sup0 / dia0; inv[0] = 1.0 / dia0;
-        for (int i = 1; i < m; ++i) {
-            double sub = (i == m - 1) ? 0.0 : 1.0, dia = (i == m - 1) ? 6.0 : 4.0, sup = 1.0;
-            double den = dia - sub * cp[i - 1];
-            cp[i] = sup / den; inv[i] = 1.0 / den;
-        }
-        OFRI_TRY(ofri_cached_table(ctx, key + "c", cp.data(), m * sizeof(double), &pc));
-        OFRI_TRY(ofri_cached_table(ctx, key + "i", inv.data(), m * sizeof(double), &pi));
-    }
-    t->cp = (const double *)pc; t->inv = (const double *)pi;
-    return OFRI_OK;
-}
-
-struct SplineEvalTable { const int *k; const double *theta; };
-static int get_spline_eval(ofri_ctx *ctx, int n, int N, SplineEvalTable *t) {
-    std::string key = "se_" + std::to_string(n) + "_" + std::to_string(N);
-    void *pk = ofri_find_table(ctx, key + "k"), *pt = ofri_find_table(ctx, key + "t");
-    if (!pk || !pt) {
-        std::vector<int> k(N); std::vector<double> th(N);
-        for (long long i = 0; i < N; ++i) {
-            long long num = i * n, cap = (long long)(n - 1) * N;      // points past the last knot clamp onto it
-            if (num > cap) num = cap;
-            long long kk = num / N; if (kk > n - 2) kk = n - 2;
-            k[i] = (int)kk; th[i] = (double)(num - kk * N) / (double)N;
-        }
-        OFRI_TRY(ofri_cached_table(ctx, key + "k", k.data(), N * sizeof(int), &pk));
-        OFRI_TRY(ofri_cached_table(ctx, key + "t", th.data(), N * sizeof(double), &pt));
-    }
-    t->k = (const int *)pk; t->theta = (const double *)pt;
-    return OFRI_OK;
-}
-
-// The system is strictly diagonally dominant: a perturbation of the forward recurrence shrinks by
-// 1/(4 - cp) ~ 0.268 per step (and of the back substitution by cp ~ 0.268), so a line can be cut into
-// chunks that each start SP_WARM = 40 samples early from a zero state; the start-up error is below
-// 0.268^40 ~ 1e-23 of the values, far under float64 rounding.  Chunks run in parallel:
-// thread = (line, chunk).  Arrays are (n, L): sample k of line l at k*L + l, so consecutive threads
-// (consecutive lines) touch consecutive addresses.  Loads are issued SP_BLK steps ahead of the
-// dependent recurrence.
-#define SP_CHUNK 32
-#define SP_WARM 40
-#define SP_BLK 8
-
-template <class T>
-__global__ void __launch_bounds__(64)
-k_spline_fwd(const T *__restrict__ y, double *__restrict__ DP, int n, int L, int nchunks, SplineSolveTable t) {
-    int line = blockIdx.x * blockDim.x + threadIdx.x;
-    int chunk = blockIdx.y;
-    if (line >= L) return;
-    const int m = n - 2;
-    const int s = chunk * SP_CHUNK, e = (chunk == nchunks - 1) ? m : s + SP_CHUNK;
-    const int w = s - SP_WARM > 0 ? s - SP_WARM : 0;
-    const T *yl = y + line;
-    double *dl = DP + line;
-    double y0 = (double)yl[(size_t)w * L], y1 = (double)yl[(size_t)(w + 1) * L], prev = 0.0;
-    for (int i0 = w; i0 < e; i0 += SP_BLK) {
-        double yn[SP_BLK], iv[SP_BLK];
-#pragma unroll
-        for (int u = 0; u < SP_BLK; ++u) {
-            int i = i0 + u < e ? i0 + u : e - 1;
-            yn[u] = (double)yl[(size_t)(i + 2) * L];
-            iv[u] = t.inv[i];
-        }
-#pragma unroll
-        for (int u = 0; u < SP_BLK; ++u) {
-            int i = i0 + u;
-            if (i < e) {
-                double rhs = 6.0 * (y0 - 2.0 * y1 + yn[u]);
-                double sub = (i == 0 || i == m - 1) ? 0.0 : 1.0;
-                double dp = (rhs - sub * prev) * iv[u];
-                if (i >= s) dl[(size_t)(i + 1) * L] = dp;
-                prev = dp; y0 = y1; y1 = yn[u];
-            }
-        }
-    }
-}
-
-__global__ void __launch_bounds__(64)
-k_spline_bwd(const double *__restrict__ DP, double *__restrict__ M, int n, int L, int nchunks, SplineSolveTable t) {
-    int line = blockIdx.x * blockDim.x + threadIdx.x;
-    int chunk = blockIdx.y;
-    if (line >= L) return;
-    const int m = n - 2;
-    const int s = chunk * SP_CHUNK, e = (chunk == nchunks - 1) ? m : s + SP_CHUNK;
-    const int we = e - 1 + SP_WARM < m - 1 ? e - 1 + SP_WARM : m - 1;
-    const double *dl = DP + line;
-    double *ml = M + line;
-    // unknown i lives at array index i+1; the last unknown equals its forward value exactly
-    double next = dl[(size_t)(we + 1) * L];
-    if (we < e) ml[(size_t)(we + 1) * L] = next;
-    // unknowns s and s+1 (closing relation of chunk 0); with only two unknowns the second is the start value
-    double m_first = 0.0, m_second = (we == s + 1) ? next : 0.0;
-    double m_last = next, m_last2 = 0.0;       // unknowns m-1 and m-2 (last chunk)
-    for (int i0 = we - 1; i0 >= s; i0 -= SP_BLK) {
-        double dv[SP_BLK], cv[SP_BLK];
-#pragma unroll
-        for (int u = 0; u < SP_BLK; ++u) {
-            int i = i0 - u >= s ? i0 - u : s;
-            dv[u] = dl[(size_t)(i + 1) * L];
-            cv[u] = t.cp[i];
-        }
-#pragma unroll
-        for (int u = 0; u < SP_BLK; ++u) {
-            int i = i0 - u;
-            if (i >= s) {
-                double v = dv[u] - cv[u] * next;
-                if (i < e) ml[(size_t)(i + 1) * L] = v;
-                if (i == m - 2) m_last2 = v;
-                if (i == s + 1) m_second = v;
-                if (i == s) m_first = v;
-                next = v;
-            }
-        }
-    }
-    if (chunk == 0) ml[0] = 2.0 * m_first - m_second;                          // M[0] = 2M[1] - M[2]
-    if (chunk == nchunks - 1) ml[(size_t)(n - 1) * L] = 2.0 * m_last - m_last2;   // M[n-1] = 2M[n-2] - M[n-3]
-}
-
-template <class T>
-static int spline_solve(ofri_ctx *ctx, const T *y, double *DP, double *M, int n, int L, const SplineSolveTable &t) {
-    const int m = n - 2;
-    int nchunks = m / SP_CHUNK;
-    if (nchunks < 1) nchunks = 1;
-    dim3 g(ceil_div(L, 64), nchunks);
-    k_spline_fwd<T><<<g, 64, 0, ctx->stream>>>(y, DP, n, L, nchunks, t);
-    OFRI_LAUNCH_CHECK();
-    k_spline_bwd<<<g, 64, 0, ctx->stream>>>(DP, M, n, L, nchunks, t);
-    OFRI_LAUNCH_CHECK();
-    return OFRI_OK;
-}
-
-__device__ __forceinline__ double spline_val(double ya, double yb, double Ma, double Mb, double th) {
-    double A = 1.0 - th, B = th;
-    return A * ya + B * yb + ((A * A * A - A) * Ma + (B * B * B - B) * Mb) / 6.0;
-}
-
-// Evaluate every line at N points and store the result TRANSPOSED: in (n, L) -> out (L, N), through a
-// padded LDS tile so that both the loads (along lines) and the stores (along samples) are coalesced.
-template <class TI, class TO>
-__global__ void __launch_bounds__(256)
-k_spline_eval_T(const TI *__restrict__ y, const double *__restrict__ M, TO *__restrict__ out, int n, int N, int L,
-                SplineEvalTable t, float post_scale, int do_scale) {
-    __shared__ double tile[32][33];
-    const int l0 = blockIdx.x * 32, i0 = blockIdx.y * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        int i = i0 + ty + 8 * r, l = l0 + tx;
-        if (i < N && l < L) {
-            int k = t.k[i];
-            double th = t.theta[i];
-            size_t a = (size_t)k * L + l, b = a + L;
-            tile[ty + 8 * r][tx] = spline_val((double)y[a], (double)y[b], M[a], M[b], th);
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        int l = l0 + ty + 8 * r, i = i0 + tx;
-        if (i < N && l < L) {
-            double v = tile[tx][ty + 8 * r];
-            if (sizeof(TO) == 4) {
-                float f = (float)v;
-                out[(size_t)l * N + i] = (TO)(do_scale ? __fmul_rn(f, post_scale) : f);
-            } else {
-                out[(size_t)l * N + i] = (TO)v;
-            }
-        }
-    }
-}
-
-extern "C" int ofri_spline_upsample(ofri_ctx *ctx, const float *src, int rows_in, int cols_in,
-                                    float *dst, int rows_out, int cols_out, float post_scale) {
-    OFRI_TRY(ofri_check_ctx(ctx));
-    OFRI_REQUIRE(src && dst && src != dst, "null or aliased pointer");
-    OFRI_REQUIRE(rows_in >= 4 && cols_in >= 4, "cubic spline needs at least 4 samples per axis (got %d x %d)", rows_in, cols_in);
-    OFRI_REQUIRE(rows_out > 0 && cols_out > 0, "bad output shape");
-    SplineSolveTable s0, s1;
-    SplineEvalTable e0, e1;
-    OFRI_TRY(get_spline_solve(ctx, rows_in, &s0));
-    OFRI_TRY(get_spline_solve(ctx, cols_in, &s1));
-    OFRI_TRY(get_spline_eval(ctx, rows_in, rows_out, &e0));
-    OFRI_TRY(get_spline_eval(ctx, cols_in, cols_out, &e1));
-    const size_t big = (size_t)rows_out * cols_in * sizeof(double);
-    PoolBuf M0(ctx), Tt(ctx), M1(ctx), DP(ctx);
-    OFRI_TRY(M0.get((size_t)rows_in * cols_in * sizeof(double)));
-    OFRI_TRY(Tt.get(big));
-    OFRI_TRY(M1.get(big));
-    OFRI_TRY(DP.get(big));
-    // axis 0: the lines are the cols_in columns of src (rows_in samples each); the result is stored
-    // transposed, Tt = (cols_in, rows_out), so that axis 1 becomes the sample axis of the next stage
-    OFRI_TRY(spline_solve<float>(ctx, src, DP.as<double>(), M0.as<double>(), rows_in, cols_in, s0));
-    {
-        dim3 g(ceil_div(cols_in, 32), ceil_div(rows_out, 32));
-        k_spline_eval_T<float, double><<<g, 256, 0, ctx->stream>>>(src, M0.as<double>(), Tt.as<double>(), rows_in, rows_out,
-                                                                   cols_in, e0, 1.0f, 0);
-        OFRI_LAUNCH_CHECK();
-    }
-    // axis 1: the lines are the rows_out columns of Tt (cols_in samples each); transposed store gives
-    // the row-major (rows_out, cols_out) result
-    OFRI_TRY(spline_solve<double>(ctx, Tt.as<double>(), DP.as<double>(), M1.as<double>(), cols_in, rows_out, s1));
-    {
-        dim3 g(ceil_div(rows_out, 32), ceil_div(cols_out, 32));
-        k_spline_eval_T<double, float><<<g, 256, 0, ctx->stream>>>(Tt.as<double>(), M1.as<double>(), dst, cols_in, cols_out,
-                                                                   rows_out, e1, post_scale, post_scale != 1.0f);
-        OFRI_LAUNCH_CHECK();
-    }
-    return OFRI_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
