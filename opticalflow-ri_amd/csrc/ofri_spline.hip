@@ -84,39 +84,28 @@ template <int NK, int PB, bool CAPTURE, bool INTERIOR, class F>
 __device__ __forceinline__ void spline_line(double (&D)[NK + 2 + SP_WARM], double *S, int a, int n, double lam,
                                             const SplineFactors &fa, F sample) {
     constexpr int ND = NK + 2 + SP_WARM, NSTEP = ND + SP_WARM;
-    constexpr int NB = (NSTEP + PB - 1) / PB;      // samples are fetched PB steps ahead of the recurrence
     using T = decltype(sample(0));
     const int i0 = a - 3;                          // D[j] is unknown i0 + j (unknown i is M[i+1])
     const int s0 = i0 - SP_WARM;                   // step st handles unknown s0 + st and takes in sample s0 + st + 2
-    T cur[PB], nxt[PB];
+    T ring[PB];                                    // PB loads in flight ahead of the recurrence
     const T r0 = sample(s0), r1 = sample(s0 + 1);
 #pragma unroll
-    for (int u = 0; u < PB; ++u) nxt[u] = sample(s0 + 2 + u);
+    for (int u = 0; u < PB; ++u) ring[u] = sample(s0 + 2 + u);
     double y0 = (double)r0, y1 = (double)r1, prev = 0.0;
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
-#pragma unroll
-        for (int u = 0; u < PB; ++u) cur[u] = nxt[u];
-#pragma unroll
-        for (int u = 0; u < PB; ++u)
-            if ((b + 1) * PB + u < NSTEP) nxt[u] = sample(s0 + 2 + (b + 1) * PB + u);
-        asm volatile("" ::: "memory");             // keeps the table reads of later blocks from piling up here
-#pragma unroll
-        for (int u = 0; u < PB; ++u) {
-            const int st = b * PB + u, tt = st - SP_WARM;
-            if (st < NSTEP) {
-                // branch-free: outside [0, m-1] the factor is 0, so the value is 0 and the chain restarts
-                const int i = s0 + st;
-                const double yn = (double)cur[u];
-                if (CAPTURE && tt >= 1 && tt <= NK) S[tt - 1] = yn;
-                double iv = lam, carry = prev;
-                if (!INTERIOR) { iv = fa.iv[i - fa.fb]; carry = fa.cm[i - fa.fb] * prev; }
-                const double dp = (6.0 * (y0 - 2.0 * y1 + yn) - carry) * iv;
-                prev = dp;
-                if (tt >= 0) D[tt] = dp;
-                y0 = y1; y1 = yn;
-            }
-        }
+    for (int st = 0; st < NSTEP; ++st) {
+        const int u = st % PB, tt = st - SP_WARM, i = s0 + st;
+        const double yn = (double)ring[u];
+        if (st + PB < NSTEP) ring[u] = sample(s0 + 2 + st + PB);
+        asm volatile("" ::: "memory");             // keeps the loads in step with the recurrence
+        if (CAPTURE && tt >= 1 && tt <= NK) S[tt - 1] = yn;
+        // branch-free: outside [0, m-1] the factor is 0, so the value is 0 and the chain restarts
+        double iv = lam, carry = prev;
+        if (!INTERIOR) { iv = fa.iv[i - fa.fb]; carry = fa.cm[i - fa.fb] * prev; }
+        const double dp = (6.0 * (y0 - 2.0 * y1 + yn) - carry) * iv;
+        prev = dp;
+        if (tt >= 0) D[tt] = dp;
+        y0 = y1; y1 = yn;
     }
     // back substitution from unknown min(i0 + ND - 1, m - 1), which keeps its forward value; entries outside
     // [0, m-1] are 0 from the forward sweep and stay 0
@@ -218,38 +207,36 @@ k_spline_xsolve(const float *__restrict__ Y, double *__restrict__ Mx, int n_r, i
 // A workgroup takes YE_CELLS knot intervals in y and YE_COLS knot columns (YE_COLS-1 intervals in x); its two
 // wavefronts are the two arrays, Y and Mx.  Thread (column, array) reads its column straight from memory
 // (lanes = consecutive columns) and solves it in registers.  The evaluation goes by quarters of the tile:
-// the thread parks (sample, second derivative) of the quarter's knots in LDS, so that the knot interval of a
-// fine row can be a run-time index; then, in batches of YE_FB fine rows, every thread puts g (from Y, My) or
-// gxx (from Mx, Mxy) of its column into LDS and, after a barrier, turns the batch into the output pixels of
-// one fine column.  Row weights and knot intervals of the tile's fine rows are staged in LDS once.
-#define YE_CELLS 32
+// for every fine row of the quarter the thread puts g (from Y, My) or gxx (from Mx, Mxy) of its column into
+// LDS (knot intervals are compile-time positions in the registers; the first two fine rows of an interval are
+// straight-line code, further ones - factors above 2 - a loop), and after a barrier every thread turns the
+// rows into the output pixels of one fine column.  Row weights of the tile's fine rows are staged in LDS.
+#define YE_CELLS 36
 #define YE_NK (YE_CELLS + 1)
 #define YE_COLS 64
 #define YE_NT (2 * YE_COLS)
-#define YE_FB 8
-#define YE_Q 8                      // knot intervals per quarter
+#define YE_Q 9                      // knot intervals per quarter
+#define YE_GR 24                    // fine rows per pass over a quarter (one pass up to a factor of 3)
+#define YE_EB 8                     // fine rows a thread turns into pixels at a time
 #define YE_WROWS 96                 // fine rows whose weights are staged at a time
-#define YE_PB 8
+#define YE_PB 12
 template <bool SCALE>
 __global__ void __launch_bounds__(YE_NT, 2)
 k_spline_ysolve_eval(const float *__restrict__ Y, const double *__restrict__ Mx, float *__restrict__ out, int n_r,
                      int n_c, int N_c, SplineSolveTable ts, SplineAxisTable ay, SplineAxisTable ax, float post_scale) {
-    static_assert(YE_CELLS % YE_Q == 0 && YE_WROWS >= 2 * YE_FB, "tile shape");
-    __shared__ double2 KN[YE_Q + 1][YE_NT];           // (sample, second derivative) of the quarter's knots
-    __shared__ double G[2][YE_FB][2][YE_COLS];
+    static_assert(YE_CELLS % YE_Q == 0 && YE_WROWS >= YE_GR && YE_GR % YE_EB == 0, "tile shape");
+    __shared__ double G[YE_GR + 1][2][YE_COLS];       // last row: sink for the rows an interval does not have
     __shared__ double WR[YE_WROWS][4];
-    __shared__ int KR[YE_WROWS];
     __shared__ double fac[3][YE_NK + 2 + 2 * SP_WARM];
     const int tid = threadIdx.x, arr = __builtin_amdgcn_readfirstlane(tid / YE_COLS), cl = tid % YE_COLS;
     const int tx0 = blockIdx.x * (YE_COLS - 1), a = blockIdx.y * YE_CELLS;
     const int c = min(tx0 + cl, n_c - 1);
-    const int ibase0 = ay.first[a], N_r = ay.first[n_r - 1];
+    const int N_r = ay.first[n_r - 1];
     const bool inner = spline_interior<YE_NK>(a, n_r, ts.settle);
-    int wbase = ibase0;                               // WR, KR hold the fine rows wbase .. wbase + YE_WROWS - 1
+    int wbase = ay.first[a];                          // WR holds the fine rows wbase .. wbase + YE_WROWS - 1
     auto stage_rows = [&]() {
         for (int r = tid; r < YE_WROWS; r += YE_NT) {
             const size_t i = (size_t)min(wbase + r, N_r - 1);
-            KR[r] = ay.k[i];
             WR[r][0] = ay.w[4 * i]; WR[r][1] = ay.w[4 * i + 1]; WR[r][2] = ay.w[4 * i + 2]; WR[r][3] = ay.w[4 * i + 3];
         }
     };
@@ -275,53 +262,79 @@ k_spline_ysolve_eval(const float *__restrict__ Y, const double *__restrict__ Mx,
     const int cmine = ax.k[jmine] - tx0;
     const double xa = ax.w[4 * (size_t)jmine], xb = ax.w[4 * (size_t)jmine + 1], xal = ax.w[4 * (size_t)jmine + 2],
                  xbe = ax.w[4 * (size_t)jmine + 3];
-    auto emit = [&](int j, int cc, double wa, double wb, double wal, double wbe, int buf, int ib, int nr) {
-        double v[YE_FB];
+    // rows i0 .. i0+nr-1 (nr <= YE_EB) from G[g0 ...] to fine column j
+    auto emit = [&](int j, int cc, double wa, double wb, double wal, double wbe, int g0, int i0, int nr) {
+        double v[YE_EB];
 #pragma unroll
-        for (int r = 0; r < YE_FB; ++r) {
-            const double *g = &G[buf][r][0][cc], *h = &G[buf][r][1][cc];
+        for (int r = 0; r < YE_EB; ++r) {
+            const double *g = &G[g0 + r][0][cc], *h = &G[g0 + r][1][cc];
             v[r] = wa * g[0] + wb * g[1] + wal * h[0] + wbe * h[1];
         }
 #pragma unroll
-        for (int r = 0; r < YE_FB; ++r) {
+        for (int r = 0; r < YE_EB; ++r) {
             float f = (float)v[r];
             if (SCALE) f = __fmul_rn(f, post_scale);
-            if (r < nr) out[(size_t)(ib + r) * N_c + j] = f;
+            if (r < nr) out[(size_t)(i0 + r) * N_c + j] = f;
         }
     };
-    __syncthreads();                                  // WR, KR staged
-    int buf = 0;
+    auto row_value = [&](int li, double ya, double yb, double Ma, double Mb) {
+        const double *w = WR[min(max(li, 0), YE_WROWS - 1)];
+        return w[0] * ya + w[1] * yb + w[2] * Ma + w[3] * Mb;
+    };
+    __syncthreads();                                  // WR staged
 #pragma unroll
     for (int q = 0; q < YE_CELLS / YE_Q; ++q) {
         const int k0 = a + q * YE_Q;                  // first knot interval of the quarter
         if (k0 > n_r - 2) break;
-        // KN[p][tid] is written and read by this thread only
+        int f[YE_Q + 1];                              // fine rows of interval k0 + p: f[p] .. f[p+1]-1
 #pragma unroll
-        for (int p = 0; p <= YE_Q; ++p) KN[p][tid] = make_double2(S[q * YE_Q + p], D[q * YE_Q + p + 2]);
-        const int rq1 = ay.first[min(k0 + YE_Q, n_r - 1)];
-        // One barrier per batch is enough: the next batch is written to the other half of G, and nobody gets
-        // past the barrier after that before everyone has read this one.
-        for (int ib = ay.first[k0]; ib < rq1; ib += YE_FB, buf ^= 1) {
-            const int nr = min(YE_FB, rq1 - ib);
-            if (ib + YE_FB > wbase + YE_WROWS) {      // (factors above 2) move the window of staged row weights
-                __syncthreads();
-                wbase = ib;
+        for (int p = 0; p <= YE_Q; ++p) f[p] = ay.first[min(k0 + p, n_r - 1)];
+        for (int pb = f[0]; pb < f[YE_Q]; pb += YE_GR) {
+            const int pe = min(pb + YE_GR, f[YE_Q]);
+            if (pe > wbase + YE_WROWS) {              // (factors above 2) move the window of staged row weights
+                wbase = pb;
                 stage_rows();
                 __syncthreads();
             }
+            bool more = false;
+            // weights of the first two fine rows of an interval, fetched one interval ahead of their use
+            double wa[4], wb[4];
+            auto fetch = [&](int p) {
+                const double *ra = WR[min(max(max(f[p], pb) - wbase, 0), YE_WROWS - 1)];
+                const double *rb = WR[min(max(max(f[p], pb) + 1 - wbase, 0), YE_WROWS - 1)];
 #pragma unroll
-            for (int r = 0; r < YE_FB; ++r) {
-                const int li = min(ib + r, rq1 - 1) - wbase;          // rows past the batch repeat its last row
-                const int kl = KR[li] - k0;
-                const double2 P = KN[kl][tid], Q = KN[kl + 1][tid];
-                G[buf][r][arr][cl] = WR[li][0] * P.x + WR[li][1] * Q.x + WR[li][2] * P.y + WR[li][3] * Q.y;
+                for (int e = 0; e < 4; ++e) { wa[e] = ra[e]; wb[e] = rb[e]; }
+            };
+            fetch(0);
+#pragma unroll
+            for (int p = 0; p < YE_Q; ++p) {
+                const int lo = max(f[p], pb), n = min(f[p + 1], pe) - lo;
+                const double ya = S[q * YE_Q + p], yb = S[q * YE_Q + p + 1], Ma = D[q * YE_Q + p + 2], Mb = D[q * YE_Q + p + 3];
+                const double ga = wa[0] * ya + wa[1] * yb + wa[2] * Ma + wa[3] * Mb;
+                const double gb = wb[0] * ya + wb[1] * yb + wb[2] * Ma + wb[3] * Mb;
+                if (p + 1 < YE_Q) fetch(p + 1);
+                G[n >= 1 ? lo - pb : YE_GR][arr][cl] = ga;
+                G[n >= 2 ? lo + 1 - pb : YE_GR][arr][cl] = gb;
+                more |= n > 2;
+            }
+            if (more) {
+#pragma unroll
+                for (int p = 0; p < YE_Q; ++p) {
+                    const int lo = max(f[p], pb), hi = min(f[p + 1], pe);
+                    const double ya = S[q * YE_Q + p], yb = S[q * YE_Q + p + 1], Ma = D[q * YE_Q + p + 2], Mb = D[q * YE_Q + p + 3];
+                    for (int i = lo + 2; i < hi; ++i) G[i - pb][arr][cl] = row_value(i - wbase, ya, yb, Ma, Mb);
+                }
             }
             __syncthreads();
-            if (jf0 + tid < jf1) emit(jf0 + tid, cmine, xa, xb, xal, xbe, buf, ib, nr);
-            for (int j = jf0 + tid + YE_NT; j < jf1; j += YE_NT) {        // more than two fine columns per knot interval
-                const double *w = ax.w + 4 * (size_t)j;
-                emit(j, ax.k[j] - tx0, w[0], w[1], w[2], w[3], buf, ib, nr);
+            for (int rb = 0; rb < pe - pb; rb += YE_EB) {
+                const int nr = min(YE_EB, pe - pb - rb);
+                if (jf0 + tid < jf1) emit(jf0 + tid, cmine, xa, xb, xal, xbe, rb, pb + rb, nr);
+                for (int j = jf0 + tid + YE_NT; j < jf1; j += YE_NT) {     // more than two fine columns per knot interval
+                    const double *w = ax.w + 4 * (size_t)j;
+                    emit(j, ax.k[j] - tx0, w[0], w[1], w[2], w[3], rb, pb + rb, nr);
+                }
             }
+            __syncthreads();                          // G is rewritten by the next pass
         }
     }
 }
