@@ -183,7 +183,12 @@ k_hs_stream(SlPlanes in, float *__restrict__ Uo, float *__restrict__ Vo, int H, 
     __shared__ float4 ring[SL_NS][2][2][32];      // ring[s]: input rows of stage s.  [row & 1][U|V][lane]
     __shared__ float4 coef[SL_CR][4][32];         // [row slot][fx|fy|ft|1/den][lane]
     const int tid = threadIdx.x;
-    const int strip = blockIdx.x % tiles_x, chunk = blockIdx.x / tiles_x;
+    // Workgroups go to the 8 XCDs round-robin by index, and each XCD has its own L2.  Renumber them so that an
+    // XCD gets a run of neighbouring strips and chunks: the columns and fill rows that neighbours share are then
+    // fetched from memory once per XCD instead of once per workgroup.
+    const int nb = gridDim.x, per = nb / 8;
+    const int bid = blockIdx.x < per * 8 ? (blockIdx.x % 8) * per + blockIdx.x / 8 : blockIdx.x;
+    const int strip = bid % tiles_x, chunk = bid / tiles_x;
     const int ya = chunk * chunk_rows, yb = min(H, ya + chunk_rows);
     const int x0 = strip * SL_OX - SL_NL;          // image x of strip column 0
     const int rho0 = ya - SL_NL;                   // first input row of the chunk

@@ -126,6 +126,9 @@ __global__ void k_resample_x_rows(const float *__restrict__ in, int H, int W_in,
 // resamples along x the input rows the tile's y-windows cover (float64 accumulation, rounded to float32 as
 // Pillow stores its intermediate image) into LDS, then along y out of LDS.  Same arithmetic, same bits as
 // the two separate passes; the intermediate image never goes to memory.
+// x pass: wavefront w takes the input rows rlo + w, rlo + w + 4, ...; a row segment goes through the
+// wavefront's own LDS line (written and read by that wavefront only, so no workgroup barrier), and the
+// segments of the next two rows are already on their way in registers.
 #define RF_TX 64
 #define RF_TY 16
 #define RF_ROWS 48                       // input rows a tile may need (16 outputs at 2:1 need 38)
@@ -134,11 +137,11 @@ __global__ void __launch_bounds__(256)
 k_resize_fused(const float *__restrict__ in, int H_in, int W_in, float *__restrict__ out, int H_out, int W_out,
                ResampleTable tx, ResampleTable ty) {
     __shared__ float hrow[RF_ROWS][RF_TX];
-    __shared__ float seg[2][4][RF_SEG];                                // input row segments, double buffered
-    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;           // 64 x 4: one wavefront per input row
+    __shared__ float seg[4][RF_SEG];                                   // one input row segment per wavefront
+    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;           // 64 x 4
     const int xb = blockIdx.x * RF_TX, x = xb + lx, y0 = blockIdx.y * RF_TY;
     const int ylast = min(y0 + RF_TY, H_out) - 1, xlast = min(xb + RF_TX, W_out) - 1;
-    const int rlo = ty.bounds[2 * y0], rhi = ty.bounds[2 * ylast] + ty.bounds[2 * ylast + 1];   // uniform
+    const int rlo = ty.bounds[2 * y0], rhi = min(ty.bounds[2 * ylast] + ty.bounds[2 * ylast + 1], rlo + RF_ROWS);   // uniform
     const int xlo = tx.bounds[2 * xb], span = min(tx.bounds[2 * xlast] + tx.bounds[2 * xlast + 1] - xlo, RF_SEG);
     double w[9];
     int off[9];
@@ -153,21 +156,30 @@ k_resize_fused(const float *__restrict__ in, int H_in, int W_in, float *__restri
             w[i] = i < cnt ? k[i * ks] : 0.0;
         }
     }
-    int buf = 0;
-    for (int r0 = rlo; r0 < rhi; r0 += 4, buf ^= 1) {
-        const int r = r0 + ly;
-        const bool live = r < rhi && r - rlo < RF_ROWS;                 // second test: never past the LDS rows
-        if (live) {
-            const float *row = in + (size_t)r * W_in + xlo;
-            for (int i = lx; i < span; i += 64) seg[buf][ly][i] = row[i];
-        }
-        __syncthreads();
-        if (live) {
-            double ss = 0.0;
+    // columns lx, lx + 64, lx + 128 of the segment; rows past the tile's last repeat it (and are not used)
+    const int c0 = min(lx, span - 1), c1 = min(lx + 64, span - 1), c2 = min(lx + 128, span - 1);
+    auto fetch = [&](int r, float &v0, float &v1, float &v2) {
+        const float *row = in + (size_t)min(r, rhi - 1) * W_in + xlo;
+        v0 = row[c0]; v1 = row[c1]; v2 = row[c2];
+    };
+    float a0, a1, a2, b0, b1, b2, n0, n1, n2;
+    fetch(rlo + ly, a0, a1, a2);
+    fetch(rlo + ly + 4, b0, b1, b2);
+    float *line = seg[ly];
+    for (int r = rlo + ly; r < rhi; r += 4) {
+        fetch(r + 8, n0, n1, n2);
+        line[lx] = a0; line[lx + 64] = a1;
+        if (lx + 128 < RF_SEG) line[lx + 128] = a2;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        double ss = 0.0;
 #pragma unroll
-            for (int i = 0; i < 9; ++i) ss = __dadd_rn(ss, __dmul_rn((double)seg[buf][ly][off[i]], w[i]));
-            hrow[r - rlo][lx] = (float)ss;
-        }
+        for (int i = 0; i < 9; ++i) ss = __dadd_rn(ss, __dmul_rn((double)line[off[i]], w[i]));
+        hrow[r - rlo][lx] = (float)ss;
+        __builtin_amdgcn_wave_barrier();                                // the line is rewritten after these reads
+        a0 = b0; a1 = b1; a2 = b2;
+        b0 = n0; b1 = n1; b2 = n2;
     }
     __syncthreads();
     if (x >= W_out) return;
