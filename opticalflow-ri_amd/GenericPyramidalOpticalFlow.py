@@ -172,6 +172,10 @@ def pyramidal_flow_device(im1, im2, FILTER, mainOFlowAlgoAdapter, pyramidalLevel
                 else:
                     work1, work2, Uacc, Vacc, U, V = next_level_device(work1, work1.shape, work2, Uacc, Vacc,
                                                                        warping, biLinear, False)
+            if opt is None and Uacc is not None and not VERBOSE and getattr(main, "can_accumulate", False):
+                # the adapter adds its increment to the running sum itself (in its last launch's stores)
+                main.accumulate_device(work1, work2, U, V, Uacc, Vacc)
+                continue
             U, V, err = _compute(main, work1, work2, U, V)
             _say(main.getAlgoName() + ' estimated error for image registration: ' + str(err))
             if opt is not None:

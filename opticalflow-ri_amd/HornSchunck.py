@@ -21,11 +21,22 @@ class HSOpticalFlowAlgoAdapter(object):
         return HS(im1, im2, alpha, self.Niter, U, V)
 
     accepts_zero_flow_as_none = True     # compute_device takes U = V = None for a zero initial flow
+    can_accumulate = True                # accumulate_device adds the new flow to the driver's running sum itself
 
     def compute_device(self, im1, im2, U, V, want_error=False):
         """Device-resident form used by the pyramid driver: DeviceArrays in, DeviceArrays out."""
         alpha = self.alphas.pop()
         return hs_device(im1, im2, alpha, self.Niter, U, V, want_error)
+
+    def accumulate_device(self, im1, im2, U, V, Uacc, Vacc):
+        """compute_device followed by Uacc += U, Vacc += V (the driver's accumulation,
+        GenericPyramidalOpticalFlow.py:414-415) in one call; nothing is returned."""
+        alpha = self.alphas.pop()
+        ctx = im1.ctx
+        rows, cols = im1.shape
+        _ofri.check(_ofri.lib().ofri_hs_compute_acc(ctx.handle, im1.ptr, im2.ptr, U.ptr if U is not None else None,
+                                                    V.ptr if V is not None else None, Uacc.ptr, Vacc.ptr,
+                                                    float(alpha), int(self.Niter), rows, cols))
 
     def getAlgoName(self):
         return 'Horn-Schunck'

@@ -162,7 +162,8 @@ int ofri_hs_fused_launch(ofri_ctx *ctx, const float *su, const float *sv, float 
                          const float *fy, const float *ft, float a2, int T, int H, int W);
 
 int ofri_hs_fused_launch_pitched(ofri_ctx *ctx, const float *su, const float *sv, float *du, float *dv, const float *fx,
-                                 const float *fy, const float *ft, float a2, int T, int H, int W, int pin, int pc, int pout);
+                                 const float *fy, const float *ft, float a2, int T, int H, int W, int pin, int pc, int pout,
+                                 bool accumulate);
 
 extern "C" int ofri_hs_set_fuse(ofri_ctx *ctx, int sweeps_per_launch) {
     OFRI_REQUIRE(ctx, "null context");
@@ -200,9 +201,11 @@ static int hs_stream_share(ofri_ctx *ctx, const void *const *ptrs, int nptrs, in
 // n_stream sweeps through the pipeline, the remaining niter - n_stream (fewer than 12) through the tile kernel
 // reading the pipeline's plane set.  Coefficients: dense fx, fy, ft, or (fx == nullptr) differentiated from
 // the frames straight into the set.  Filling the set is not part of the timing records.
+// accumulate (needs niter > n_stream): the result is added to what (Uout, Vout) hold, in the last launch's stores.
 static int hs_stream_path(ofri_ctx *ctx, const float *Uin, const float *Vin, float *Uout, float *Vout, const float *fx,
                           const float *fy, const float *ft, const float *first, const float *second, float a2, int niter,
-                          int n_stream, int rows, int cols) {
+                          int n_stream, int rows, int cols, bool accumulate = false) {
+    OFRI_REQUIRE(!accumulate || niter > n_stream, "accumulating store needs left-over sweeps");
     PoolBuf buf(ctx);
     OFRI_TRY(buf.get(ofri_sl_bytes(rows, cols)));
     OfriSlSet set;
@@ -222,7 +225,7 @@ static int hs_stream_path(ofri_ctx *ctx, const float *Uin, const float *Vin, flo
             const int T = remaining < Tmax ? remaining : Tmax;
             const bool last = k == L - 1;
             OFRI_TRY(ofri_hs_fused_launch_pitched(ctx, set.U[cur], set.V[cur], last ? Uout : set.U[cur ^ 1], last ? Vout : set.V[cur ^ 1],
-                                                  set.fx, set.fy, set.ft, a2, T, rows, cols, set.P, set.P, last ? cols : set.P));
+                                                  set.fx, set.fy, set.ft, a2, T, rows, cols, set.P, set.P, last ? cols : set.P, last && accumulate));
             cur ^= 1;
             remaining -= T;
         }
@@ -332,6 +335,26 @@ extern "C" int ofri_hs_compute(ofri_ctx *ctx, const float *frame0, const float *
         *err_host = (r[0] + r[1]) / ((double)rows * (double)cols);
     }
     return OFRI_OK;
+}
+
+extern "C" int ofri_hs_compute_acc(ofri_ctx *ctx, const float *frame0, const float *frame1, const float *U_in,
+                                   const float *V_in, float *U_acc, float *V_acc, float alpha, int niter, int rows, int cols) {
+    OFRI_TRY(ofri_check_ctx(ctx));
+    OFRI_REQUIRE(frame0 && frame1 && U_acc && V_acc, "null pointer");
+    OFRI_REQUIRE((U_in == nullptr) == (V_in == nullptr), "U_in and V_in must both be given or both be null");
+    OFRI_REQUIRE(U_acc != U_in && V_acc != V_in && U_acc != V_acc && U_acc != V_in && V_acc != U_in, "accumulator must not alias input");
+    OFRI_REQUIRE(rows > 0 && cols > 0 && niter >= 0, "bad shape or niter");
+    const void *q[6] = {frame0, frame1, U_in, V_in, U_acc, V_acc};
+    const int n_stream = hs_stream_share(ctx, q, 6, niter, rows, cols);
+    if (n_stream > 0 && niter > n_stream)      // the left-over sweeps' launch adds into the accumulator as it stores
+        return hs_stream_path(ctx, U_in, V_in, U_acc, V_acc, nullptr, nullptr, nullptr, frame1, frame0, alpha * alpha, niter,
+                              n_stream, rows, cols, true);
+    const size_t n = (size_t)rows * cols;
+    PoolBuf tu(ctx), tv(ctx);
+    OFRI_TRY(tu.get(n * sizeof(float))); OFRI_TRY(tv.get(n * sizeof(float)));
+    OFRI_TRY(ofri_hs_compute(ctx, frame0, frame1, U_in, V_in, tu.as<float>(), tv.as<float>(), alpha, niter, rows, cols, nullptr));
+    OFRI_TRY(ofri_add_inplace(ctx, U_acc, tu.as<float>(), n));
+    return ofri_add_inplace(ctx, V_acc, tv.as<float>(), n);
 }
 
 extern "C" int ofri_prof_enable(ofri_ctx *ctx, int on) {

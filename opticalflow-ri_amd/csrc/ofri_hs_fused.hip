@@ -88,7 +88,7 @@ __device__ __forceinline__ void ft_sweep(float4 (&edge)[2][FT_BANDS + 2][2][2][3
 __global__ void __launch_bounds__(256, 2)
 k_hs_fused(const float *__restrict__ U, const float *__restrict__ V, const float *__restrict__ fx,
            const float *__restrict__ fy, const float *__restrict__ ft, float *__restrict__ Un,
-           float *__restrict__ Vn, float a2, int H, int W, int T, int tiles_x, int ntiles, int pin, int pc, int pout) {
+           float *__restrict__ Vn, float a2, int H, int W, int T, int tiles_x, int ntiles, int pin, int pc, int pout, int accumulate) {
     // [buffer][slot][top/bottom][U/V][lane]; slot b+1 belongs to band b, slots 0 and FT_BANDS+1 are never written
     __shared__ float4 edge[2][FT_BANDS + 2][2][2][32];
     __shared__ float4 ftile[FT_RY][32];          // ft of the region: read-only after the load, kept out of registers
@@ -162,8 +162,14 @@ k_hs_fused(const float *__restrict__ U, const float *__restrict__ V, const float
             int y = gyb + r;
             if (y < H) {
                 size_t o = (size_t)y * pout + gx0;
-                *reinterpret_cast<float4 *>(Un + o) = make_float4(cu[r][0], cu[r][1], cu[r][2], cu[r][3]);
-                *reinterpret_cast<float4 *>(Vn + o) = make_float4(cv[r][0], cv[r][1], cv[r][2], cv[r][3]);
+                float4 ou = make_float4(cu[r][0], cu[r][1], cu[r][2], cu[r][3]), ov = make_float4(cv[r][0], cv[r][1], cv[r][2], cv[r][3]);
+                if (accumulate) {               // the destination holds the flow so far: add the increment to it
+                    const float4 pu = *reinterpret_cast<const float4 *>(Un + o), pv = *reinterpret_cast<const float4 *>(Vn + o);
+                    ou = make_float4(__fadd_rn(pu.x, ou.x), __fadd_rn(pu.y, ou.y), __fadd_rn(pu.z, ou.z), __fadd_rn(pu.w, ou.w));
+                    ov = make_float4(__fadd_rn(pv.x, ov.x), __fadd_rn(pv.y, ov.y), __fadd_rn(pv.z, ov.z), __fadd_rn(pv.w, ov.w));
+                }
+                *reinterpret_cast<float4 *>(Un + o) = ou;
+                *reinterpret_cast<float4 *>(Vn + o) = ov;
             }
         }
     }
@@ -179,15 +185,16 @@ int ofri_hs_fused_max_sweeps(void) { return FT_HALO; }
 
 // One launch: T <= FT_HALO sweeps from (su, sv) into (du, dv); source and destination must differ.  Every
 // pointer is at pixel (0,0) of its plane; pin, pc, pout are the row pitches (in floats, multiples of 4) of the
-// source, coefficient and destination planes.
+// source, coefficient and destination planes.  accumulate: the result is added to what (du, dv) hold.
 int ofri_hs_fused_launch_pitched(ofri_ctx *ctx, const float *su, const float *sv, float *du, float *dv, const float *fx,
-                                 const float *fy, const float *ft, float a2, int T, int H, int W, int pin, int pc, int pout) {
+                                 const float *fy, const float *ft, float a2, int T, int H, int W, int pin, int pc, int pout,
+                                 bool accumulate) {
     const int tiles_x = ceil_div(W, FT_OX), tiles_y = ceil_div(H, FT_OY), ntiles = tiles_x * tiles_y;
-    k_hs_fused<<<ntiles, 256, 0, ctx->stream>>>(su, sv, fx, fy, ft, du, dv, a2, H, W, T, tiles_x, ntiles, pin, pc, pout);
+    k_hs_fused<<<ntiles, 256, 0, ctx->stream>>>(su, sv, fx, fy, ft, du, dv, a2, H, W, T, tiles_x, ntiles, pin, pc, pout, accumulate ? 1 : 0);
     OFRI_LAUNCH_CHECK();
     return OFRI_OK;
 }
 int ofri_hs_fused_launch(ofri_ctx *ctx, const float *su, const float *sv, float *du, float *dv, const float *fx,
                          const float *fy, const float *ft, float a2, int T, int H, int W) {
-    return ofri_hs_fused_launch_pitched(ctx, su, sv, du, dv, fx, fy, ft, a2, T, H, W, W, W, W);
+    return ofri_hs_fused_launch_pitched(ctx, su, sv, du, dv, fx, fy, ft, a2, T, H, W, W, W, W, false);
 }

@@ -157,6 +157,25 @@ def test_hs_launch_shapes_agree_bitwise(ctx, shape, nit):
         np.testing.assert_array_equal(out[fuse][0], out[1][0]); np.testing.assert_array_equal(out[fuse][1], out[1][1])
 
 
+@pytest.mark.parametrize("shape,nit,zero", [((64, 96), 20, False), ((2048, 2048), 28, True), ((2048, 2052), 28, False),
+                                            ((2048, 2048), 24, True)])
+def test_hs_accumulating_step_equals_step_plus_add(ctx, shape, nit, zero):
+    """ofri_hs_compute_acc (the driver's Uaccum += U folded into the last launch's stores on large fields, a
+    separate add elsewhere) gives the bits of ofri_hs_compute followed by the float32 addition."""
+    from HornSchunck import HSOpticalFlowAlgoAdapter, hs_device
+    from piv_synth import synth_piv
+    a, b = synth_piv(shape[0], shape[1], seed=3)
+    rng = np.random.default_rng(nit)
+    acc = [rng.standard_normal(shape).astype(np.float32) for _ in range(2)]
+    start = [None, None] if zero else [ctx.upload(rng.standard_normal(shape).astype(np.float32) * 0.1) for _ in range(2)]
+    fa, fb = ctx.upload(a.astype(np.float32)), ctx.upload(b.astype(np.float32))
+    Un, Vn, _ = hs_device(fa, fb, 21.0, nit, start[0], start[1], want_error=False)
+    want = (acc[0] + Un.numpy(), acc[1] + Vn.numpy())
+    Ua, Va = ctx.upload(acc[0]), ctx.upload(acc[1])
+    HSOpticalFlowAlgoAdapter([21.0], nit).accumulate_device(fa, fb, start[0], start[1], Ua, Va)
+    np.testing.assert_array_equal(Ua.numpy(), want[0]); np.testing.assert_array_equal(Va.numpy(), want[1])
+
+
 def test_hs_zero_iterations_returns_input(ctx):
     import HornSchunck as H
     rng = np.random.default_rng(1)
