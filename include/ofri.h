@@ -126,11 +126,22 @@ int ofri_hs_compute(ofri_ctx *ctx, const float *frame0, const float *frame1,
                     const float *U_in, const float *V_in, float *U_out, float *V_out,
                     float alpha, int niter, int rows, int cols, double *err_host);
 /* The same step as the driver uses it when no second algorithm refines the level: the new flow is an increment
- * that the driver adds to the flow accumulated so far (Uaccum += U, src/GenericPyramidalOpticalFlow.py:414-415).
+ * that the driver adds to the flow accumulated so far (Uaccum += U, src/GenericPyramidalOpticalFlow.py:413-414).
  * U_acc, V_acc are updated in place with the same float32 additions; on large fields the last sweep launch does
  * them as it stores, which saves a pass over four planes. */
 int ofri_hs_compute_acc(ofri_ctx *ctx, const float *frame0, const float *frame1, const float *U_in,
                         const float *V_in, float *U_acc, float *V_acc, float alpha, int niter, int rows, int cols);
+/* One pyramid level of the driver with Horn-Schunck as its only algorithm (src/GenericPyramidalOpticalFlow.py:
+ * 200-201 warp, 374-375 pre-filter, 406 adapter step from a zero flow, 413-414 accumulation), on the level's
+ * images as resized, before warp and filter.
+ *   warp = 0 (first level): U_flow, V_flow receive the flow of the filtered pair.
+ *   warp = 1: both images are warped by half of (U_flow, V_flow) in opposite directions, as ofri_warp_pair does,
+ *             filtered, and the new flow is added to U_flow, V_flow.
+ * taps_host: ntaps float32 filter taps as for ofri_gauss_sep (ntaps = 0: no filter).  Same bits as
+ * ofri_warp_pair, ofri_gauss_sep twice and ofri_hs_compute(_acc) called one after the other; on large fields with
+ * 3, 5 or 7 taps the warped and filtered images are never written to memory. */
+int ofri_hs_level(ofri_ctx *ctx, const float *im1, const float *im2, float *U_flow, float *V_flow,
+                  const float *taps_host, int ntaps, int warp, float alpha, int niter, int rows, int cols);
 
 /* ---- Liu-Shen physics-based refinement --------------------------------------------------------- */
 /* physicsBasedOpticalFlowLiuShen(im1, im2, h, U, V) (src/PhysicsBasedOpticalFlowLiuShen.py:82-158)
@@ -211,7 +222,7 @@ int ofri_warp_pair(ofri_ctx *ctx, const float *im1, const float *im2, const floa
  * IndexError text in ofri_last_error().  out may equal im (the reference overwrites its argument). */
 int ofri_warp_shift_ofe(ofri_ctx *ctx, const float *im, const float *U, const float *V, float *out,
                         int rows, int cols, const float *taps_host, int ntaps);
-/* acc += x  (Uaccum += U, src/GenericPyramidalOpticalFlow.py:414-415);  y *= s */
+/* acc += x  (Uaccum += U, src/GenericPyramidalOpticalFlow.py:413-414);  y *= s */
 int ofri_add_inplace(ofri_ctx *ctx, float *acc, const float *x, size_t n);
 int ofri_scale_inplace(ofri_ctx *ctx, float *y, float s, size_t n);
 /* (|a-b|_F) as float64 to the host (b may be NULL: |a|_F); max over a float32 array */

@@ -58,13 +58,10 @@ def shift_warp_device(im, us, vs):
     return out
 
 
-def next_level_device(im1, prev_shape, im2, Uacc, Vacc, warping=True, biLinear=True, scale=False):
-    """Level transition (reference updateNextPyramidalLevel, :118-235) on device arrays.  After a warp the
-    new level starts from a zero flow (:224-225), returned as U = V = None (see _compute).  With
-    warping and not biLinear the reference overwrites its first image; here the first returned array is
-    that image and the argument is left alone."""
-    ctx = im1.ctx
-    H, W = im1.shape
+def upsample_flow_device(Uacc, Vacc, shape, prev_shape, scale):
+    """The flow so far on the next level's grid (reference :152-162, scaling :147-150 and :163-175)."""
+    ctx = Uacc.ctx
+    H, W = shape
     sx = np.float32(np.float32(W) / np.float32(prev_shape[1])) if scale else np.float32(1.0)
     sy = np.float32(np.float32(H) / np.float32(prev_shape[0])) if scale else np.float32(1.0)
     if tuple(prev_shape) != (H, W):
@@ -78,6 +75,17 @@ def next_level_device(im1, prev_shape, im2, Uacc, Vacc, warping=True, biLinear=T
                 _ofri.check(_ofri.lib().ofri_scale_inplace(ctx.handle, us.ptr, float(sx), us.size))
             if sy != 1.0:
                 _ofri.check(_ofri.lib().ofri_scale_inplace(ctx.handle, vs.ptr, float(sy), vs.size))
+    return us, vs
+
+
+def next_level_device(im1, prev_shape, im2, Uacc, Vacc, warping=True, biLinear=True, scale=False):
+    """Level transition (reference updateNextPyramidalLevel, :118-235) on device arrays.  After a warp the
+    new level starts from a zero flow (:224-225), returned as U = V = None (see _compute).  With
+    warping and not biLinear the reference overwrites its first image; here the first returned array is
+    that image and the argument is left alone."""
+    ctx = im1.ctx
+    H, W = im1.shape
+    us, vs = upsample_flow_device(Uacc, Vacc, (H, W), prev_shape, scale)
     if not warping:
         return im1, im2, ctx.zeros((H, W)), ctx.zeros((H, W)), us, vs
     if not biLinear:
@@ -127,6 +135,10 @@ def pyramidal_flow_device(im1, im2, FILTER, mainOFlowAlgoAdapter, pyramidalLevel
 
     taps = prepareGaussianKernel(FILTER, 3) if FILTER > 1e-3 else None
     taps_opt = prepareGaussianKernel(FILTER_OPT, 5) if (opt is not None and FILTER_OPT > 1e-3) else None
+    # Horn-Schunck alone, one pass per level, bilinear warp: the adapter takes the level's images as resized and
+    # runs warp, pre-filter, its step and the accumulation itself (fused into fewer passes over memory)
+    whole_level = (opt is None and kLevels == 1 and warping and biLinear and taps is not None and not VERBOSE
+                   and getattr(main, "can_run_level", False))
     scale = 1.0 / (2.0 ** (pyramidalLevels - 1))
     work1 = work2 = None
     U = V = Uacc = Vacc = None
@@ -141,6 +153,15 @@ def pyramidal_flow_device(im1, im2, FILTER, mainOFlowAlgoAdapter, pyramidalLevel
             raise Exception('Invalid scale level: ' + str(scale))
         else:
             n1, n2 = im1, im2
+        if whole_level:
+            if level > 1:
+                Uacc, Vacc = upsample_flow_device(Uacc, Vacc, n1.shape, prev.shape, lscale)
+            else:
+                Uacc, Vacc = ctx.empty(n1.shape), ctx.empty(n1.shape)
+            main.level_device(n1, n2, Uacc, Vacc, taps, warp=level > 1)
+            work1 = n1                                # the next level asks for this level's shape only
+            scale *= 2
+            continue
         if level > 1:
             w1, w2, Uacc, Vacc, U, V = next_level_device(n1, prev.shape, n2, Uacc, Vacc, warping, biLinear, lscale)
             if warping and not biLinear:

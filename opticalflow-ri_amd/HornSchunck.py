@@ -30,13 +30,26 @@ class HSOpticalFlowAlgoAdapter(object):
 
     def accumulate_device(self, im1, im2, U, V, Uacc, Vacc):
         """compute_device followed by Uacc += U, Vacc += V (the driver's accumulation,
-        GenericPyramidalOpticalFlow.py:414-415) in one call; nothing is returned."""
+        GenericPyramidalOpticalFlow.py:413-414) in one call; nothing is returned."""
         alpha = self.alphas.pop()
         ctx = im1.ctx
         rows, cols = im1.shape
         _ofri.check(_ofri.lib().ofri_hs_compute_acc(ctx.handle, im1.ptr, im2.ptr, U.ptr if U is not None else None,
                                                     V.ptr if V is not None else None, Uacc.ptr, Vacc.ptr,
                                                     float(alpha), int(self.Niter), rows, cols))
+
+    can_run_level = True                 # level_device runs warp, pre-filter, step and accumulation of a level
+
+    def level_device(self, im1, im2, Uflow, Vflow, taps, warp):
+        """One pyramid level on its resized images (GenericPyramidalOpticalFlow.py:200-201 warp, 374-375
+        pre-filter, 406 step from a zero flow, 413-414 accumulation).  warp False: Uflow, Vflow receive the
+        flow; warp True: the images are warped by them and the new flow is added to them."""
+        alpha = self.alphas.pop()
+        ctx = im1.ctx
+        rows, cols = im1.shape
+        taps = np.ascontiguousarray(taps, dtype=np.float32)
+        _ofri.check(_ofri.lib().ofri_hs_level(ctx.handle, im1.ptr, im2.ptr, Uflow.ptr, Vflow.ptr, taps.ctypes.data,
+                                              int(taps.size), 1 if warp else 0, float(alpha), int(self.Niter), rows, cols))
 
     def getAlgoName(self):
         return 'Horn-Schunck'

@@ -1,17 +1,10 @@
 // Separable Gaussian pre-filter.  Reference behaviour: src/gaussian_filter.py:24-94.
 #include "ofri_internal.h"
+#include "ofri_image_math.h"
 #include <cmath>
 
 #define GAUSS_MAX_TAPS 127
 
-// Border rule of the reference's pad (gaussian_filter.py:63-66,75-78).  Left of the line the samples are
-// mirrored with the edge sample repeated (-1 -> 0, -2 -> 1); right of it the reference copies the last
-// K/2 samples in their ORIGINAL order (n -> n-h, n+1 -> n-h+1, ...), which equals the mirror only for K = 3.
-__device__ __forceinline__ int gauss_idx(int i, int n, int h) {
-    if (i < 0) return -i - 1;
-    if (i >= n) return i - h;
-    return i;
-}
 
 // prepareGaussianKernel (gaussian_filter.py:47-52): offsets arange(-K/2, K/2) cast to int (truncation
 // toward zero of -K/2 + i), float64 pdf stored to float32, divided by the float32 sum of the taps.

@@ -202,15 +202,19 @@ static int hs_stream_share(ofri_ctx *ctx, const void *const *ptrs, int nptrs, in
 // reading the pipeline's plane set.  Coefficients: dense fx, fy, ft, or (fx == nullptr) differentiated from
 // the frames straight into the set.  Filling the set is not part of the timing records.
 // accumulate (needs niter > n_stream): the result is added to what (Uout, Vout) hold, in the last launch's stores.
+// level: (first, second) are a pyramid level's images as the driver holds them before its warp and pre-filter;
+// both are done on the way into the set (warp by level->U, level->V unless null), and the flow starts from zero.
+struct HsLevelFill { const float *U, *V, *taps_host; int ntaps; };
 static int hs_stream_path(ofri_ctx *ctx, const float *Uin, const float *Vin, float *Uout, float *Vout, const float *fx,
                           const float *fy, const float *ft, const float *first, const float *second, float a2, int niter,
-                          int n_stream, int rows, int cols, bool accumulate = false) {
+                          int n_stream, int rows, int cols, bool accumulate = false, const HsLevelFill *level = nullptr) {
     OFRI_REQUIRE(!accumulate || niter > n_stream, "accumulating store needs left-over sweeps");
     PoolBuf buf(ctx);
     OFRI_TRY(buf.get(ofri_sl_bytes(rows, cols)));
     OfriSlSet set;
     ofri_sl_layout(buf.as<float>(), rows, cols, &set);
-    OFRI_TRY(ofri_sl_fill(ctx, set, Uin, Vin, fx, fy, ft, first, second, a2, rows, cols));
+    if (level) OFRI_TRY(ofri_sl_fill_level(ctx, set, first, second, level->U, level->V, level->taps_host, level->ntaps, a2, rows, cols));
+    else OFRI_TRY(ofri_sl_fill(ctx, set, Uin, Vin, fx, fy, ft, first, second, a2, rows, cols));
     int rest = niter - n_stream, cur = 0, launches = 0;
     ofri_ctx::ProfRec rec{};
     OFRI_TRY(prof_begin(ctx, rec));
@@ -355,6 +359,40 @@ extern "C" int ofri_hs_compute_acc(ofri_ctx *ctx, const float *frame0, const flo
     OFRI_TRY(ofri_hs_compute(ctx, frame0, frame1, U_in, V_in, tu.as<float>(), tv.as<float>(), alpha, niter, rows, cols, nullptr));
     OFRI_TRY(ofri_add_inplace(ctx, U_acc, tu.as<float>(), n));
     return ofri_add_inplace(ctx, V_acc, tv.as<float>(), n);
+}
+
+extern "C" int ofri_hs_level(ofri_ctx *ctx, const float *im1, const float *im2, float *U_flow, float *V_flow,
+                             const float *taps_host, int ntaps, int warp, float alpha, int niter, int rows, int cols) {
+    OFRI_TRY(ofri_check_ctx(ctx));
+    OFRI_REQUIRE(im1 && im2 && U_flow && V_flow && U_flow != V_flow, "null or aliased pointer");
+    OFRI_REQUIRE(ntaps == 0 || (taps_host && (ntaps & 1)), "taps: none or an odd count expected, got %d", ntaps);
+    OFRI_REQUIRE(rows > 0 && cols > 0 && niter >= 0, "bad shape or niter");
+    const void *q[4] = {im1, im2, U_flow, V_flow};
+    const int n_stream = hs_stream_share(ctx, q, 4, niter, rows, cols);
+    if (n_stream > 0 && ofri_sl_level_ok(ntaps) && (!warp || niter > n_stream)) {
+        const HsLevelFill lf = {warp ? U_flow : nullptr, warp ? V_flow : nullptr, taps_host, ntaps};
+        // computeDerivatives takes (im2, im1) of the adapter's (im1, im2)   (HornSchunck.py:37,73,84)
+        return hs_stream_path(ctx, nullptr, nullptr, U_flow, V_flow, nullptr, nullptr, nullptr, im2, im1, alpha * alpha, niter,
+                              n_stream, rows, cols, warp != 0, &lf);
+    }
+    // smaller fields, other filter lengths: the same steps one after the other
+    const size_t bytes = (size_t)rows * cols * sizeof(float);
+    PoolBuf w1(ctx), w2(ctx);
+    const float *a = im1, *b = im2;
+    if (warp) {
+        OFRI_TRY(w1.get(bytes)); OFRI_TRY(w2.get(bytes));
+        OFRI_TRY(ofri_warp_pair(ctx, im1, im2, U_flow, V_flow, w1.as<float>(), w2.as<float>(), rows, cols));
+        a = w1.as<float>(); b = w2.as<float>();
+    }
+    PoolBuf f1(ctx), f2(ctx);
+    if (ntaps > 0) {
+        OFRI_TRY(f1.get(bytes)); OFRI_TRY(f2.get(bytes));
+        OFRI_TRY(ofri_gauss_sep(ctx, a, f1.as<float>(), rows, cols, taps_host, ntaps));
+        OFRI_TRY(ofri_gauss_sep(ctx, b, f2.as<float>(), rows, cols, taps_host, ntaps));
+        a = f1.as<float>(); b = f2.as<float>();
+    }
+    if (warp) return ofri_hs_compute_acc(ctx, a, b, nullptr, nullptr, U_flow, V_flow, alpha, niter, rows, cols);
+    return ofri_hs_compute(ctx, a, b, nullptr, nullptr, U_flow, V_flow, alpha, niter, rows, cols, nullptr);
 }
 
 extern "C" int ofri_prof_enable(ofri_ctx *ctx, int on) {

@@ -31,12 +31,9 @@ __device__ __forceinline__ void hs_update(float ua, float va, float fx, float fy
 // in float64 and rounds to float32; the reference then adds the two images' results in float32.
 // All weights are +-0.25, so a float64 sum of the four taps scaled by 0.25 reproduces it exactly.
 // P = first image, Q = second image, dense with W columns.
-__device__ __forceinline__ void hs_derivs_at(const float *__restrict__ P, const float *__restrict__ Q, int y, int x, int H, int W,
-                                             float &fx, float &fy, float &ft) {
-    const int x1 = x + 1 < W ? x + 1 : (W > 1 ? W - 2 : 0), y1 = y + 1 < H ? y + 1 : (H > 1 ? H - 2 : 0);   // reflect-101
-    const size_t r0 = (size_t)y * W, r1 = (size_t)y1 * W;
-    const double p00 = P[r0 + x], p01 = P[r0 + x1], p10 = P[r1 + x], p11 = P[r1 + x1];
-    const double q00 = Q[r0 + x], q01 = Q[r0 + x1], q10 = Q[r1 + x], q11 = Q[r1 + x1];
+// The arithmetic, on the 2x2 neighbourhoods p (first image) and q (second image): [row][column] = 00, 01, 10, 11.
+__device__ __forceinline__ void hs_derivs_of(double p00, double p01, double p10, double p11, double q00, double q01, double q10,
+                                             double q11, float &fx, float &fy, float &ft) {
     const float pfx = (float)(0.25 * (((p00 - p01) + p10) - p11));
     const float qfx = (float)(0.25 * (((q00 - q01) + q10) - q11));
     const float pfy = (float)(0.25 * (((p00 + p01) - p10) - p11));
@@ -46,4 +43,12 @@ __device__ __forceinline__ void hs_derivs_at(const float *__restrict__ P, const 
     fx = __fadd_rn(pfx, qfx);
     fy = __fadd_rn(pfy, qfy);
     ft = __fadd_rn(qft, pft);
+}
+// partner index of the 2x2 window at the far edge ('mirror' = reflect-101)
+__device__ __forceinline__ int hs_next101(int i, int n) { return i + 1 < n ? i + 1 : (n > 1 ? n - 2 : 0); }
+__device__ __forceinline__ void hs_derivs_at(const float *__restrict__ P, const float *__restrict__ Q, int y, int x, int H, int W,
+                                             float &fx, float &fy, float &ft) {
+    const int x1 = hs_next101(x, W), y1 = hs_next101(y, H);
+    const size_t r0 = (size_t)y * W, r1 = (size_t)y1 * W;
+    hs_derivs_of(P[r0 + x], P[r0 + x1], P[r1 + x], P[r1 + x1], Q[r0 + x], Q[r0 + x1], Q[r1 + x], Q[r1 + x1], fx, fy, ft);
 }

@@ -19,3 +19,7 @@ int ofri_sl_fill(ofri_ctx *ctx, OfriSlSet &s, const float *U, const float *V, co
                  const float *ft, const float *first, const float *second, float a2, int H, int W);
 int ofri_sl_sweeps(ofri_ctx *ctx, OfriSlSet &s, int n, bool to_dense, float *Uout, float *Vout, int H, int W,
                    int *cur, int *launches);
+// the same from a pyramid level's images: warp (if U, V are given), pre-filter, derivatives in one pass
+bool ofri_sl_level_ok(int ntaps);
+int ofri_sl_fill_level(ofri_ctx *ctx, OfriSlSet &s, const float *first, const float *second, const float *U, const float *V,
+                       const float *taps_host, int ntaps, float a2, int H, int W);

@@ -1,6 +1,7 @@
 // Pyramid glue: Pillow-compatible resampling and the bilinear warps (spline flow upsampling: ofri_spline.hip).
 // Reference behaviour: src/GenericPyramidalOpticalFlow.py:67-235.
 #include "ofri_internal.h"
+#include "ofri_image_math.h"
 #include <cmath>
 #include <string>
 #include <vector>
@@ -275,28 +276,7 @@ extern "C" int ofri_resize_bilinear(ofri_ctx *ctx, const float *src, int rows_in
 }
 
 // ---------------------------------------------------------------------------------------------
-// Bilinear warp, clamp-to-edge.  The reference rounds the coordinate to the nearest integer (half to
-// even), takes the neighbour on the side of the residual and weights by |residual|, all in float64
-// (float32 coordinate minus int32 index promotes to float64), then stores float32.
-__device__ __forceinline__ float warp_sample(const float *__restrict__ img, int H, int W, float cy, float cx) {
-    float ry = rintf(cy), rx = rintf(cx);
-    // int32 conversion of the rounded coordinate; coordinates this far out are clamped anyway
-    int iy = (int)fminf(fmaxf(ry, -2147483000.f), 2147483000.f);
-    int ix = (int)fminf(fmaxf(rx, -2147483000.f), 2147483000.f);
-    double dy = (double)cy - (double)iy, dx = (double)cx - (double)ix;
-    int ny = dy < 0 ? iy - 1 : iy + 1, nx = dx < 0 ? ix - 1 : ix + 1;
-    dy = fabs(dy); dx = fabs(dx);
-    iy = clampi(iy, 0, H - 1); ny = clampi(ny, 0, H - 1);
-    ix = clampi(ix, 0, W - 1); nx = clampi(nx, 0, W - 1);
-    double a = (double)img[(size_t)iy * W + ix], b = (double)img[(size_t)iy * W + nx];
-    double c = (double)img[(size_t)ny * W + ix], d = (double)img[(size_t)ny * W + nx];
-    double r = __dmul_rn(__dmul_rn(1.0 - dy, 1.0 - dx), a);
-    r = __dadd_rn(r, __dmul_rn(__dmul_rn(1.0 - dy, dx), b));
-    r = __dadd_rn(r, __dmul_rn(__dmul_rn(dy, 1.0 - dx), c));
-    r = __dadd_rn(r, __dmul_rn(__dmul_rn(dy, dx), d));
-    return (float)r;
-}
-
+// Bilinear warp, clamp-to-edge: warp_sample in ofri_image_math.h.
 __global__ void k_warp_coords(const float *__restrict__ img, const float *__restrict__ cy, const float *__restrict__ cx,
                               float *__restrict__ out, int H, int W) {
     int x = blockIdx.x * blockDim.x + threadIdx.x;

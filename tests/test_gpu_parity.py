@@ -176,6 +176,42 @@ def test_hs_accumulating_step_equals_step_plus_add(ctx, shape, nit, zero):
     np.testing.assert_array_equal(Ua.numpy(), want[0]); np.testing.assert_array_equal(Va.numpy(), want[1])
 
 
+@pytest.mark.parametrize("shape,ksize,warp,nit", [((2048, 2048), 3, True, 28), ((2048, 2048), 3, False, 28), ((2050, 2052), 5, True, 16),
+                                                   ((2049, 2052), 7, True, 28), ((2049, 2052), 7, False, 24), ((96, 128), 3, True, 20),
+                                                   ((2048, 2048), 9, True, 28)])
+def test_hs_whole_level_equals_its_steps(ctx, shape, ksize, warp, nit):
+    """ofri_hs_level (warp, pre-filter, derivatives in one pass on large fields) against ofri_warp_pair,
+    ofri_gauss_sep twice, ofri_hs_compute and the float32 accumulation one after the other: same bits, with a
+    flow large enough to push samples over every edge of the image."""
+    import _ofri
+    from HornSchunck import HSOpticalFlowAlgoAdapter, hs_device
+    from gaussian_filter import prepareGaussianKernel
+    from piv_synth import synth_piv
+    lib = _ofri.lib()
+    H, W = shape
+    a, b = synth_piv(H, W, seed=5)
+    rng = np.random.default_rng(ksize + nit)
+    flow = [(rng.standard_normal(shape) * 3.0).astype(np.float32) for _ in range(2)]
+    taps = prepareGaussianKernel(3.4, ksize)
+    da, db = ctx.upload(a.astype(np.float32)), ctx.upload(b.astype(np.float32))
+    # the steps one after the other
+    if warp:
+        U0, V0 = ctx.upload(flow[0]), ctx.upload(flow[1])
+        w1, w2 = ctx.empty(shape), ctx.empty(shape)
+        _ofri.check(lib.ofri_warp_pair(ctx.handle, da.ptr, db.ptr, U0.ptr, V0.ptr, w1.ptr, w2.ptr, H, W))
+    else:
+        w1, w2 = da, db
+    f1, f2 = ctx.empty(shape), ctx.empty(shape)
+    for src, dst in ((w1, f1), (w2, f2)):
+        _ofri.check(lib.ofri_gauss_sep(ctx.handle, src.ptr, dst.ptr, H, W, taps.ctypes.data, int(taps.size)))
+    Un, Vn, _ = hs_device(f1, f2, 21.0, nit, None, None, want_error=False)
+    want = (flow[0] + Un.numpy(), flow[1] + Vn.numpy()) if warp else (Un.numpy(), Vn.numpy())
+    # the whole level
+    Uf, Vf = (ctx.upload(flow[0]), ctx.upload(flow[1])) if warp else (ctx.empty(shape), ctx.empty(shape))
+    HSOpticalFlowAlgoAdapter([21.0], nit).level_device(da, db, Uf, Vf, taps, warp)
+    np.testing.assert_array_equal(Uf.numpy(), want[0]); np.testing.assert_array_equal(Vf.numpy(), want[1])
+
+
 def test_hs_zero_iterations_returns_input(ctx):
     import HornSchunck as H
     rng = np.random.default_rng(1)
