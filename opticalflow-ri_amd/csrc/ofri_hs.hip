@@ -192,8 +192,8 @@ static int hs_stream_share(ofri_ctx *ctx, const void *const *ptrs, int nptrs, in
     size_t bits = 0;
     for (int i = 0; i < nptrs; ++i) bits |= (size_t)ptrs[i];
     if ((bits & 15) != 0 || (cols & 3) != 0 || cols < 8 || niter <= 0) return 0;
-    const int per = ofri_hs_stream_sweeps();
     if (ctx->hs_fuse == 16) return niter;
+    const int per = ofri_hs_stream_sweeps();
     if (ctx->hs_fuse == 0 && ofri_hs_stream_pays(rows, cols) && niter >= 2 * per) return niter / per * per;
     return 0;
 }
@@ -201,14 +201,13 @@ static int hs_stream_share(ofri_ctx *ctx, const void *const *ptrs, int nptrs, in
 // n_stream sweeps through the pipeline, the remaining niter - n_stream (fewer than 12) through the tile kernel
 // reading the pipeline's plane set.  Coefficients: dense fx, fy, ft, or (fx == nullptr) differentiated from
 // the frames straight into the set.  Filling the set is not part of the timing records.
-// accumulate (needs niter > n_stream): the result is added to what (Uout, Vout) hold, in the last launch's stores.
+// accumulate: the result is added to what (Uout, Vout) hold, in the last launch's stores.
 // level: (first, second) are a pyramid level's images as the driver holds them before its warp and pre-filter;
 // both are done on the way into the set (warp by level->U, level->V unless null), and the flow starts from zero.
 struct HsLevelFill { const float *U, *V, *taps_host; int ntaps; };
 static int hs_stream_path(ofri_ctx *ctx, const float *Uin, const float *Vin, float *Uout, float *Vout, const float *fx,
                           const float *fy, const float *ft, const float *first, const float *second, float a2, int niter,
                           int n_stream, int rows, int cols, bool accumulate = false, const HsLevelFill *level = nullptr) {
-    OFRI_REQUIRE(!accumulate || niter > n_stream, "accumulating store needs left-over sweeps");
     PoolBuf buf(ctx);
     OFRI_TRY(buf.get(ofri_sl_bytes(rows, cols)));
     OfriSlSet set;
@@ -218,7 +217,7 @@ static int hs_stream_path(ofri_ctx *ctx, const float *Uin, const float *Vin, flo
     int rest = niter - n_stream, cur = 0, launches = 0;
     ofri_ctx::ProfRec rec{};
     OFRI_TRY(prof_begin(ctx, rec));
-    OFRI_TRY(ofri_sl_sweeps(ctx, set, n_stream, rest == 0, Uout, Vout, rows, cols, &cur, &launches));
+    OFRI_TRY(ofri_sl_sweeps(ctx, set, n_stream, rest == 0, rest == 0 && accumulate, Uout, Vout, rows, cols, &cur, &launches));
     OFRI_TRY(prof_end(ctx, rec, rows, cols, launches, n_stream));
     if (rest > 0) {
         const int Tmax = ofri_hs_fused_max_sweeps(), L = (rest + Tmax - 1) / Tmax;
@@ -350,7 +349,7 @@ extern "C" int ofri_hs_compute_acc(ofri_ctx *ctx, const float *frame0, const flo
     OFRI_REQUIRE(rows > 0 && cols > 0 && niter >= 0, "bad shape or niter");
     const void *q[6] = {frame0, frame1, U_in, V_in, U_acc, V_acc};
     const int n_stream = hs_stream_share(ctx, q, 6, niter, rows, cols);
-    if (n_stream > 0 && niter > n_stream)      // the left-over sweeps' launch adds into the accumulator as it stores
+    if (n_stream > 0)                          // the last launch adds into the accumulator as it stores
         return hs_stream_path(ctx, U_in, V_in, U_acc, V_acc, nullptr, nullptr, nullptr, frame1, frame0, alpha * alpha, niter,
                               n_stream, rows, cols, true);
     const size_t n = (size_t)rows * cols;
@@ -369,7 +368,7 @@ extern "C" int ofri_hs_level(ofri_ctx *ctx, const float *im1, const float *im2, 
     OFRI_REQUIRE(rows > 0 && cols > 0 && niter >= 0, "bad shape or niter");
     const void *q[4] = {im1, im2, U_flow, V_flow};
     const int n_stream = hs_stream_share(ctx, q, 4, niter, rows, cols);
-    if (n_stream > 0 && ofri_sl_level_ok(ntaps) && (!warp || niter > n_stream)) {
+    if (n_stream > 0 && ofri_sl_level_ok(ntaps)) {
         const HsLevelFill lf = {warp ? U_flow : nullptr, warp ? V_flow : nullptr, taps_host, ntaps};
         // computeDerivatives takes (im2, im1) of the adapter's (im1, im2)   (HornSchunck.py:37,73,84)
         return hs_stream_path(ctx, nullptr, nullptr, U_flow, V_flow, nullptr, nullptr, nullptr, im2, im1, alpha * alpha, niter,

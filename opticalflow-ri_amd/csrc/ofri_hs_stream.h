@@ -17,8 +17,8 @@ size_t ofri_sl_bytes(int H, int W);                    // device bytes of a plan
 void ofri_sl_layout(float *base, int H, int W, OfriSlSet *s);
 int ofri_sl_fill(ofri_ctx *ctx, OfriSlSet &s, const float *U, const float *V, const float *fx, const float *fy,
                  const float *ft, const float *first, const float *second, float a2, int H, int W);
-int ofri_sl_sweeps(ofri_ctx *ctx, OfriSlSet &s, int n, bool to_dense, float *Uout, float *Vout, int H, int W,
-                   int *cur, int *launches);
+int ofri_sl_sweeps(ofri_ctx *ctx, OfriSlSet &s, int n, bool to_dense, bool accumulate, float *Uout, float *Vout,
+                   int H, int W, int *cur, int *launches);
 // the same from a pyramid level's images: warp (if U, V are given), pre-filter, derivatives in one pass
 bool ofri_sl_level_ok(int ntaps);
 int ofri_sl_fill_level(ofri_ctx *ctx, OfriSlSet &s, const float *first, const float *second, const float *U, const float *V,

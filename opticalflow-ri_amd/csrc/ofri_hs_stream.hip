@@ -19,14 +19,20 @@
 #include "ofri_hs_math.h"
 #include "ofri_hs_stream.h"
 
-#define SL_NL 12                         // sweeps per launch = padding
-#define SL_NS (SL_NL / 2)                // pipeline stages
 #define SL_RX 128                        // strip width (32 lanes x 4 pixels)
-#define SL_OX (SL_RX - 2 * SL_NL)        // stored width
 #define SL_PF 6                          // rows the loader keeps in flight
-#define SL_LAG (3 * SL_NS)               // the last stage's second sweep runs this many rows behind the loader
-#define SL_CR SL_LAG                     // coefficient ring rows: rows rho-(SL_LAG-1) .. rho are live
-#define SL_THREADS (SL_NS * 32 + 64)
+// The depth is a template parameter.  Built: NL = 12 sweeps per launch (three stage wavefronts + loader, 48 KB of LDS,
+// three workgroups per CU).  NL = 16 (four stage wavefronts + loader, 64 KB, two workgroups per CU) was measured at
+// 327 us per launch at 4096 x 4096 against 175 us for 12 sweeps: the lost workgroup costs more than the fourth SIMD gains.
+template <int NL> struct SlCfg {
+    static constexpr int NS = NL / 2;                // pipeline stages (half-wavefronts)
+    static constexpr int OX = SL_RX - 2 * NL;        // stored width: the sweeps eat NL columns on each side
+    static constexpr int LAG = 3 * NS;               // the last stage's second sweep runs this many rows behind the loader
+    static constexpr int CR = LAG;                   // coefficient ring rows: rows rho-(LAG-1) .. rho are live
+    static constexpr int THREADS = NS * 32 + 64;
+    static constexpr int PER_CU = NL == 12 ? 3 : 2;  // workgroups per CU that the LDS allows
+};
+#define SL_NL_MAIN 12
 
 __device__ __forceinline__ float sl_left(float v) {     // lane-1 (wave_shr:1)
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xF, 0xF, true));
@@ -77,15 +83,19 @@ struct SlStage {                 // registers of one pipeline stage (one lane)
     SlRow in0, in1;              // input rows rA-1, rA
     SlRow mid0, mid1;            // rows rA-2, rA-1 of the stage's first sweep
     SlCoef gprev;                // coefficients of row rA-1
+    float4 au0, av0, au1, av1;   // (accumulating store) what the destination holds in the next two rows to store
     int rA;                      // row the first sweep produces at this step
     int cslot;                   // coefficient ring slot of row rA
 };
 
-// one step of a stage: first sweep at row rA, second sweep at row rA-1
-template <bool FULL>
-__device__ __forceinline__ void sl_stage_step(SlStage &st, float4 (&ring)[SL_NS][2][2][32], float4 (&coef)[SL_CR][4][32],
-                                              int stage, int l, bool passA, bool passB, bool store_lane, int lane_off,
-                                              float *__restrict__ rowU, float *__restrict__ rowV, bool row_ok) {
+// one step of a stage: first sweep at row rA, second sweep at row rA-1.  ACC: the last stage adds its row to what the
+// destination holds; those values are fetched two steps (rows) ahead (row2: the row two below rowU, rowV is stored later).
+template <int NL, bool FULL, bool ACC>
+__device__ __forceinline__ void sl_stage_step(SlStage &st, float4 (&ring)[SlCfg<NL>::NS][2][2][32],
+                                              float4 (&coef)[SlCfg<NL>::CR][4][32], int stage, int l, bool passA, bool passB,
+                                              bool store_lane, int lane_off, float *__restrict__ rowU, float *__restrict__ rowV,
+                                              bool row_ok, long long row2, bool row2_ok) {
+    constexpr int SL_NS = SlCfg<NL>::NS, SL_CR = SlCfg<NL>::CR;
     // newest input row rA+1, written one step ago
     const float4 nu4 = ring[stage][(st.rA + 1) & 1][0][l], nv4 = ring[stage][(st.rA + 1) & 1][1][l];
     SlCoef g;
@@ -108,10 +118,22 @@ __device__ __forceinline__ void sl_stage_step(SlStage &st, float4 (&ring)[SL_NS]
     if (stage < SL_NS - 1) {
         ring[stage + 1][rB & 1][0][l] = make_float4(out.u[0], out.u[1], out.u[2], out.u[3]);
         ring[stage + 1][rB & 1][1][l] = make_float4(out.v[0], out.v[1], out.v[2], out.v[3]);
-    } else if (store_lane && row_ok) {
-        // rowU, rowV: the output row of this step (the same for the whole workgroup, so its address is scalar work)
-        *reinterpret_cast<float4 *>(rowU + lane_off) = make_float4(out.u[0], out.u[1], out.u[2], out.u[3]);
-        *reinterpret_cast<float4 *>(rowV + lane_off) = make_float4(out.v[0], out.v[1], out.v[2], out.v[3]);
+    } else {
+        float4 ou = make_float4(out.u[0], out.u[1], out.u[2], out.u[3]), ov = make_float4(out.v[0], out.v[1], out.v[2], out.v[3]);
+        if (ACC) {
+            ou = make_float4(__fadd_rn(st.au0.x, ou.x), __fadd_rn(st.au0.y, ou.y), __fadd_rn(st.au0.z, ou.z), __fadd_rn(st.au0.w, ou.w));
+            ov = make_float4(__fadd_rn(st.av0.x, ov.x), __fadd_rn(st.av0.y, ov.y), __fadd_rn(st.av0.z, ov.z), __fadd_rn(st.av0.w, ov.w));
+            st.au0 = st.au1; st.av0 = st.av1;
+            if (store_lane && row2_ok) {
+                st.au1 = *reinterpret_cast<const float4 *>(rowU + row2 + lane_off);
+                st.av1 = *reinterpret_cast<const float4 *>(rowV + row2 + lane_off);
+            }
+        }
+        if (store_lane && row_ok) {
+            // rowU, rowV: the output row of this step (the same for the whole workgroup, so its address is scalar work)
+            *reinterpret_cast<float4 *>(rowU + lane_off) = ou;
+            *reinterpret_cast<float4 *>(rowV + lane_off) = ov;
+        }
     }
     st.in0 = st.in1; st.in1 = nw;
     st.mid0 = st.mid1; st.mid1 = mid2;
@@ -133,9 +155,10 @@ __device__ __forceinline__ float4 sl_load4(const float *__restrict__ row, const 
 // after its partner, so the row address is a scalar base plus a per-lane offset).  Rows outside the image are
 // the reflected rows.  EDGE: the strip reaches over the left or right edge of the image.  ZERO: the flow is
 // zero on input and is not read.
-template <bool EDGE, bool ZERO>
-__device__ __forceinline__ void sl_loader(const SlPlanes &in, float4 (&ring)[SL_NS][2][2][32], float4 (&coef)[SL_CR][4][32],
-                                          int tid, int x0, int rho0, int NS, int H, int W) {
+template <int NL, bool EDGE, bool ZERO>
+__device__ __forceinline__ void sl_loader(const SlPlanes &in, float4 (&ring)[SlCfg<NL>::NS][2][2][32],
+                                          float4 (&coef)[SlCfg<NL>::CR][4][32], int tid, int x0, int rho0, int NS, int H, int W) {
+    constexpr int SL_CR = SlCfg<NL>::CR;
     const int lj = tid & 31, lset = (tid >> 5) & 1;
     const int lx = x0 + 4 * lj;
     SlCols cols;                                                       // column reflection does not depend on the row
@@ -174,12 +197,14 @@ __device__ __forceinline__ void sl_loader(const SlPlanes &in, float4 (&ring)[SL_
 #undef SL_LOAD
 }
 
-// FULL: all SL_NL sweeps are wanted (no copy-through selects in the inner loop).  All planes are dense with W
-// columns (W % 4 == 0, 16-byte aligned); zero_in: the input flow is zero and in.U, in.V are not read.
-template <bool FULL>
-__global__ void __launch_bounds__(SL_THREADS)
+// FULL: all NL sweeps are wanted (no copy-through selects in the inner loop).  ACC: the result is added to what
+// (Uo, Vo) hold.  All planes are dense with W columns (W % 4 == 0, 16-byte aligned); zero_in: the input flow is
+// zero and in.U, in.V are not read.
+template <int NL, bool FULL, bool ACC>
+__global__ void __launch_bounds__(SlCfg<NL>::THREADS)
 k_hs_stream(SlPlanes in, float *__restrict__ Uo, float *__restrict__ Vo, int H, int W, int T, int tiles_x, int chunk_rows,
             int zero_in) {
+    constexpr int SL_NS = SlCfg<NL>::NS, SL_CR = SlCfg<NL>::CR, SL_LAG = SlCfg<NL>::LAG, SL_OX = SlCfg<NL>::OX, SL_NL = NL;
     __shared__ float4 ring[SL_NS][2][2][32];      // ring[s]: input rows of stage s.  [row & 1][U|V][lane]
     __shared__ float4 coef[SL_CR][4][32];         // [row slot][fx|fy|ft|1/den][lane]
     const int tid = threadIdx.x;
@@ -202,11 +227,11 @@ k_hs_stream(SlPlanes in, float *__restrict__ Uo, float *__restrict__ Vo, int H, 
     if (tid >= SL_NS * 32) {
         const bool edge = x0 < 0 || x0 + SL_RX > W;
         if (edge) {
-            if (zero_in) sl_loader<true, true>(in, ring, coef, tid, x0, rho0, NS, H, W);
-            else sl_loader<true, false>(in, ring, coef, tid, x0, rho0, NS, H, W);
+            if (zero_in) sl_loader<NL, true, true>(in, ring, coef, tid, x0, rho0, NS, H, W);
+            else sl_loader<NL, true, false>(in, ring, coef, tid, x0, rho0, NS, H, W);
         } else {
-            if (zero_in) sl_loader<false, true>(in, ring, coef, tid, x0, rho0, NS, H, W);
-            else sl_loader<false, false>(in, ring, coef, tid, x0, rho0, NS, H, W);
+            if (zero_in) sl_loader<NL, false, true>(in, ring, coef, tid, x0, rho0, NS, H, W);
+            else sl_loader<NL, false, false>(in, ring, coef, tid, x0, rho0, NS, H, W);
         }
     } else {
         // ---- stage half-wavefronts ---------------------------------------------------------------------
@@ -218,17 +243,18 @@ k_hs_stream(SlPlanes in, float *__restrict__ Uo, float *__restrict__ Vo, int H, 
             st.mid0.u[k] = st.mid0.v[k] = st.mid1.u[k] = st.mid1.v[k] = 0.f;
         }
         st.gprev.fx = st.gprev.fy = st.gprev.ft = st.gprev.rd = make_float4(0.f, 0.f, 0.f, 0.f);
+        st.au0 = st.av0 = st.au1 = st.av1 = make_float4(0.f, 0.f, 0.f, 0.f);
         st.rA = rho0 - 2 - 3 * stage;
         st.cslot = (st.rA + 64 * SL_CR) % SL_CR;
-        const bool passA = 2 * stage >= T, passB = 2 * stage + 1 >= T;    // fewer than 12 sweeps asked: copy rows through
+        const bool passA = 2 * stage >= T, passB = 2 * stage + 1 >= T;    // fewer than NL sweeps asked: copy rows through
         const bool store_lane = l >= SL_NL / 4 && l < 32 - SL_NL / 4 && (x0 + 4 * l) < W;
         const int lane_off = x0 + 4 * l;
         // six steps per round (NS is a multiple): the row registers rotate by renaming instead of moves
 #define SL_STEP(U_)                                                                                                   \
     {                                                                                                                 \
         const int ro = rho0 - SL_LAG + t + (U_);          /* row the last stage finishes at this step */              \
-        sl_stage_step<FULL>(st, ring, coef, stage, l, passA, passB, store_lane, lane_off, Uo + (long long)ro * W,     \
-                            Vo + (long long)ro * W, ro >= ya && ro < yb);                                             \
+        sl_stage_step<NL, FULL, ACC>(st, ring, coef, stage, l, passA, passB, store_lane, lane_off, Uo + (long long)ro * W, \
+                                     Vo + (long long)ro * W, ro >= ya && ro < yb, 2LL * W, ro + 2 >= ya && ro + 2 < yb); \
         __syncthreads();                                                                                              \
     }
         for (int t = 0; t < NS; t += SL_PF) { SL_STEP(0) SL_STEP(1) SL_STEP(2) SL_STEP(3) SL_STEP(4) SL_STEP(5) }
@@ -251,7 +277,7 @@ __global__ void k_sl_coefs(const float *__restrict__ ca, const float *__restrict
     o.fx[s] = gx; o.fy[s] = gy; o.ft[s] = gt; o.rd[s] = hs_rden(gx, gy, a2);
 }
 
-int ofri_hs_stream_sweeps(void) { return SL_NL; }
+int ofri_hs_stream_sweeps(void) { return SL_NL_MAIN; }
 // worth it where the row chunks are long against the pipeline's fill (2048 x 2048 pixels and up)
 bool ofri_hs_stream_pays(int H, int W) { return (long long)H * W >= 4000000LL && (W & 3) == 0; }
 
@@ -279,31 +305,43 @@ int ofri_sl_fill(ofri_ctx *ctx, OfriSlSet &s, const float *U, const float *V, co
     OFRI_LAUNCH_CHECK();
     return OFRI_OK;
 }
-// n sweeps starting from the pair *cur of the set.  to_dense: the last launch stores into (Uout, Vout);
-// otherwise the result stays in the set and *cur names its pair.
-int ofri_sl_sweeps(ofri_ctx *ctx, OfriSlSet &s, int n, bool to_dense, float *Uout, float *Vout, int H, int W,
-                   int *cur, int *launches) {
+template <int NL>
+static void sl_launch(ofri_ctx *ctx, const SlPlanes &in, float *uo, float *vo, int H, int W, int T, int zero_in, bool acc) {
+    const int tiles_x = ceil_div(W, SlCfg<NL>::OX);
+    // as many row chunks as fill the chip once with the workgroups per CU that the LDS allows
+    int nchunks = SlCfg<NL>::PER_CU * ofri_ctx_ncu(ctx) / tiles_x;
+    if (nchunks < 1) nchunks = 1;
+    const int chunk_rows = ceil_div(H, nchunks);
+    nchunks = ceil_div(H, chunk_rows);
+    const int grid = tiles_x * nchunks, thr = SlCfg<NL>::THREADS;
+    if (T == NL) {
+        if (acc) k_hs_stream<NL, true, true><<<grid, thr, 0, ctx->stream>>>(in, uo, vo, H, W, T, tiles_x, chunk_rows, zero_in);
+        else k_hs_stream<NL, true, false><<<grid, thr, 0, ctx->stream>>>(in, uo, vo, H, W, T, tiles_x, chunk_rows, zero_in);
+    } else {
+        if (acc) k_hs_stream<NL, false, true><<<grid, thr, 0, ctx->stream>>>(in, uo, vo, H, W, T, tiles_x, chunk_rows, zero_in);
+        else k_hs_stream<NL, false, false><<<grid, thr, 0, ctx->stream>>>(in, uo, vo, H, W, T, tiles_x, chunk_rows, zero_in);
+    }
+}
+
+// n sweeps starting from the pair *cur of the set (the last launch shorter if n is not a multiple of 12).
+// to_dense: the last launch stores into (Uout, Vout), adding to what they hold if accumulate; otherwise the result
+// stays in the set and *cur names its pair.
+int ofri_sl_sweeps(ofri_ctx *ctx, OfriSlSet &s, int n, bool to_dense, bool accumulate, float *Uout, float *Vout,
+                   int H, int W, int *cur, int *launches) {
     // the loader addresses V, fy, rd as U, fx, ft plus one common plane stride
     OFRI_REQUIRE(s.V[0] - s.U[0] == s.V[1] - s.U[1] && s.fy - s.fx == s.V[0] - s.U[0] && s.rd - s.ft == s.V[0] - s.U[0] &&
                      s.V[0] > s.U[0] && (s.V[0] - s.U[0]) < (1LL << 29),
                  "plane set is not laid out as U V U V fx fy ft rd");
     OFRI_REQUIRE((W & 3) == 0 && H >= 1 && W >= 4, "row-streaming pipeline needs a width that is a multiple of 4");
-    const int tiles_x = ceil_div(W, SL_OX);
-    // three workgroups per CU (48 KB of LDS each): as many row chunks as fill the chip once
-    const int ncu = ofri_ctx_ncu(ctx);
-    int nchunks = 3 * ncu / tiles_x;
-    if (nchunks < 1) nchunks = 1;
-    int chunk_rows = ceil_div(H, nchunks);
-    nchunks = ceil_div(H, chunk_rows);
-    const int L = ceil_div(n, SL_NL);
+    OFRI_REQUIRE(to_dense || !accumulate, "only a dense destination can be accumulated into");
+    const int L = ceil_div(n, SL_NL_MAIN);
     int remaining = n, c = *cur;
     for (int k = 0; k < L; ++k) {
-        const int T = remaining < SL_NL ? remaining : SL_NL;
+        const int T = remaining < SL_NL_MAIN ? remaining : SL_NL_MAIN;
         const bool dense = k == L - 1 && to_dense;
         SlPlanes in{s.U[c], s.V[c], s.fx, s.fy, s.ft, s.rd};
         float *uo = dense ? Uout : s.U[c ^ 1], *vo = dense ? Vout : s.V[c ^ 1];
-        if (T == SL_NL) k_hs_stream<true><<<tiles_x * nchunks, SL_THREADS, 0, ctx->stream>>>(in, uo, vo, H, W, T, tiles_x, chunk_rows, s.zero_in);
-        else k_hs_stream<false><<<tiles_x * nchunks, SL_THREADS, 0, ctx->stream>>>(in, uo, vo, H, W, T, tiles_x, chunk_rows, s.zero_in);
+        sl_launch<SL_NL_MAIN>(ctx, in, uo, vo, H, W, T, s.zero_in, dense && accumulate);
         OFRI_LAUNCH_CHECK();
         s.zero_in = 0;
         if (!dense) c ^= 1;

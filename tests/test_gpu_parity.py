@@ -158,7 +158,7 @@ def test_hs_launch_shapes_agree_bitwise(ctx, shape, nit):
 
 
 @pytest.mark.parametrize("shape,nit,zero", [((64, 96), 20, False), ((2048, 2048), 28, True), ((2048, 2052), 28, False),
-                                            ((2048, 2048), 24, True)])
+                                            ((2048, 2048), 24, True), ((2048, 2048), 36, False)])
 def test_hs_accumulating_step_equals_step_plus_add(ctx, shape, nit, zero):
     """ofri_hs_compute_acc (the driver's Uaccum += U folded into the last launch's stores on large fields, a
     separate add elsewhere) gives the bits of ofri_hs_compute followed by the float32 addition."""
