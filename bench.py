@@ -37,6 +37,9 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--same-device", action="store_true", help="all ranks compute on GPU 0 (rehearsal on a one-GPU box)")
     ap.add_argument("--with-transfer", action="store_true", help="also report the rate including H2D/D2H copies")
+    ap.add_argument("--graph", action="store_true", help="replay the pair's launches from a captured HIP graph (piv_plan.FlowPlan)")
+    ap.add_argument("--in-flight", type=int, default=1, help="with --graph: pairs per step, each on its own context/stream "
+                    "(small frames do not fill the GPU one pair at a time)")
     return ap.parse_args()
 
 
@@ -111,8 +114,27 @@ def main():
         except Exception as e:                       # keep the compute measurement alive
             gather, gather_note = False, "disabled: %r" % (e,)
 
+    plan = None
+    extra = []                      # further (context, plan) pairs when several frame pairs are in flight
+    if args.graph:
+        from piv_plan import FlowPlan
+        plan = FlowPlan((H, W), 3.4, lambda: HSOpticalFlowAlgoAdapter([21, 45], args.niter), pyramidalLevels=2, ctx=ctx)
+        plan.load(im0, im1)
+        for k in range(1, max(1, args.in_flight)):
+            c = _ofri.Context(dev)
+            pk = FlowPlan((H, W), 3.4, lambda: HSOpticalFlowAlgoAdapter([21, 45], args.niter), pyramidalLevels=2, ctx=c)
+            pk.load(*synth_piv(H, W, seed=100 * rank + k))
+            c.sync()
+            extra.append((c, pk))
+    pairs_per_step = 1 + len(extra)
+
     def step(i):
-        Ua, Va = pyramidal_flow_device(im0, im1, 3.4, HSOpticalFlowAlgoAdapter([21, 45], args.niter), 2, 1, None)
+        if plan is not None:
+            for _, pk in extra:
+                pk.run()
+            Ua, Va = plan.run()
+        else:
+            Ua, Va = pyramidal_flow_device(im0, im1, 3.4, HSOpticalFlowAlgoAdapter([21, 45], args.niter), 2, 1, None)
         if gather:
             buf = out_t[i & 1]
             if len(pending) >= 2:
@@ -142,6 +164,8 @@ def main():
             dist.barrier()
         else:
             ctx.sync()
+        for c, _ in extra:
+            c.sync()
 
     for i in range(args.warmup):
         step(i)
@@ -162,7 +186,7 @@ def main():
     result = None
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
-        value = world * H * W * args.steps / dt / 1e6
+        value = world * pairs_per_step * H * W * args.steps / dt / 1e6
         # dominant kernel: the Jacobi sweep launches of the full-resolution level.  A Horn-Schunck call may use
         # two kernels there (row-streaming pipeline for the multiples of 12 sweeps, tile kernel for the rest);
         # the one with the larger share of the time is reported.
@@ -194,7 +218,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "HS Fs3.4, 2-level pyramid, %dx%d synthetic Poiseuille pair, alphas [21,45], "
                                    "%d sweeps/level" % (H, W, args.niter),
-                       "pairs_per_step_per_gpu": 1, "flow_gather": gather_note,
+                       "pairs_per_step_per_gpu": pairs_per_step, "flow_gather": gather_note, "captured_graph": bool(args.graph),
                        "hs_sweeps_per_launch": sweeps_per_launch},
             "roofline": {"bound": "hbm", "kernel": "%s@%dx%d" % (kname, H, W), "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

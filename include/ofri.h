@@ -75,6 +75,22 @@ int ofri_upload_async(ofri_ctx *ctx, void *dst, const void *src_pinned_host, siz
 int ofri_download_async(ofri_ctx *ctx, void *dst_pinned_host, const void *src, size_t bytes);
 int ofri_ctx_wait(ofri_ctx *ctx, ofri_ctx *other);
 
+/* A sequence of calls captured once and replayed with one launch (a HIP graph on the context's stream).  No
+ * reference counterpart: the reference pays a Python call and an OpenCL/Numba dispatch per step; below about
+ * 2048 x 2048 pixels that, not the GPU, sets the frame rate.  Everything enqueued on the context between
+ * ofri_graph_begin and ofri_graph_end is recorded instead of run; calls that wait for the GPU (err_host, iters_host,
+ * ofri_download, ofri_ctx_sync, ofri_warp_shift_ofe) or that upload per-call host tables (Farneback, dense LK)
+ * cannot be captured and make ofri_graph_end fail.  Run the same sequence once before capturing, so that its tables
+ * exist and the pool holds its blocks.  Device memory obtained from ofri_alloc during the capture stays valid for the
+ * graph's lifetime: blocks freed inside the capture become the graph's scratch memory and are handed to nobody else;
+ * blocks still held at ofri_graph_end (the results) are the caller's to keep until the graph is destroyed.
+ * ofri_graph_launch replays on the same context; inputs are whatever the captured pointers hold at that time. */
+typedef struct ofri_graph ofri_graph;
+int ofri_graph_begin(ofri_ctx *ctx);
+int ofri_graph_end(ofri_ctx *ctx, ofri_graph **graph);
+int ofri_graph_launch(ofri_ctx *ctx, ofri_graph *graph);
+int ofri_graph_destroy(ofri_graph *graph);       /* before ofri_ctx_destroy */
+
 /* HIP events on the context's stream, for timing kernels from a host language */
 int ofri_event_create(ofri_ctx *ctx, ofri_event **ev);
 int ofri_event_record(ofri_ctx *ctx, ofri_event *ev);

@@ -45,6 +45,10 @@ _PROTOS = {
     "ofri_upload_async": ([_vp, _vp, _vp, _sz], _i),
     "ofri_download_async": ([_vp, _vp, _vp, _sz], _i),
     "ofri_ctx_wait": ([_vp, _vp], _i),
+    "ofri_graph_begin": ([_vp], _i),
+    "ofri_graph_end": ([_vp, C.POINTER(_vp)], _i),
+    "ofri_graph_launch": ([_vp, _vp], _i),
+    "ofri_graph_destroy": ([_vp], _i),
     "ofri_event_create": ([_vp, C.POINTER(_vp)], _i),
     "ofri_event_record": ([_vp, _vp], _i),
     "ofri_event_elapsed_ms": ([_vp, _vp, C.POINTER(_f)], _i),
@@ -262,9 +266,31 @@ class Context(object):
         check(lib().ofri_upload(self._h, a.ptr, arr.ctypes.data, arr.nbytes))
         return a
 
+    def upload_into(self, dst, arr):
+        """Copy a host array into the float32 DeviceArray ``dst`` (uint8/uint16 frames go raw and are widened on the GPU)."""
+        src = np.asarray(arr)
+        if tuple(src.shape) != dst.shape or dst.dtype != np.float32:
+            raise ValueError("expected an array of shape %r for a float32 destination" % (dst.shape,))
+        if src.dtype in (np.uint8, np.uint16) and src.size >= (1 << 16):
+            raw = self.upload(src, src.dtype)
+            widen = lib().ofri_u8_to_f32 if src.dtype == np.uint8 else lib().ofri_u16_to_f32
+            check(widen(self._h, raw.ptr, dst.ptr, src.size))
+            return
+        src = np.ascontiguousarray(src, dtype=np.float32)
+        check(lib().ofri_upload(self._h, dst.ptr, src.ctypes.data, src.nbytes))
+
     def wrap(self, ptr, shape, dtype=np.float32, keepalive=None):
         """Adopt external device memory (e.g. a torch tensor's data_ptr()); not freed by us."""
         return DeviceArray(self, shape, dtype, ptr=ptr, keepalive=keepalive)
+
+    # ---- captured launch sequences
+    def graph_begin(self):
+        check(lib().ofri_graph_begin(self._h))
+
+    def graph_end(self):
+        g = _vp()
+        check(lib().ofri_graph_end(self._h, C.byref(g)))
+        return Graph(self, g)
 
     # ---- timing
     def event(self):
@@ -280,6 +306,27 @@ class Context(object):
         ms = _f()
         check(lib().ofri_event_elapsed_ms(a, b, C.byref(ms)))
         return ms.value
+
+
+class Graph(object):
+    """A captured sequence of calls on a Context (Context.graph_begin / graph_end); launch() replays it."""
+
+    def __init__(self, ctx, handle):
+        self.ctx, self._g = ctx, handle
+
+    def launch(self):
+        check(lib().ofri_graph_launch(self.ctx.handle, self._g))
+
+    def close(self):
+        if self._g and self.ctx._h:
+            lib().ofri_graph_destroy(self._g)
+        self._g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class DeviceArray(object):

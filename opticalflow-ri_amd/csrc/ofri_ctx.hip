@@ -12,6 +12,13 @@ int ofri_set_error(int code, const char *fmt, ...) {
 }
 
 extern "C" int ofri_version(void) { return 100; }
+
+int ofri_stream_wait(ofri_ctx *ctx) {
+    if (ctx->capturing)
+        return ofri_set_error(OFRI_EINVAL, "this call waits for the GPU, which a captured sequence cannot do (ofri_graph_begin is active)");
+    OFRI_HIP(hipStreamSynchronize(ctx->stream));
+    return OFRI_OK;
+}
 extern "C" const char *ofri_last_error(void) { return g_err; }
 
 extern "C" int ofri_device_count(int *count) {
@@ -51,7 +58,7 @@ extern "C" int ofri_ctx_create(int device, void *stream, ofri_ctx **out) {
 
 extern "C" int ofri_pool_trim(ofri_ctx *ctx) {
     OFRI_TRY(ofri_check_ctx(ctx));
-    OFRI_HIP(hipStreamSynchronize(ctx->stream));
+    OFRI_TRY(ofri_stream_wait(ctx));
     for (auto &kv : ctx->pool)
         for (void *p : kv.second) (void)hipFree(p);
     ctx->pool.clear();
@@ -76,7 +83,7 @@ extern "C" int ofri_ctx_destroy(ofri_ctx *ctx) {
 
 extern "C" int ofri_ctx_sync(ofri_ctx *ctx) {
     OFRI_TRY(ofri_check_ctx(ctx));
-    OFRI_HIP(hipStreamSynchronize(ctx->stream));
+    OFRI_TRY(ofri_stream_wait(ctx));
     return OFRI_OK;
 }
 
@@ -97,8 +104,18 @@ extern "C" int ofri_alloc(ofri_ctx *ctx, size_t bytes, void **dptr) {
     *dptr = nullptr;
     OFRI_REQUIRE(bytes > 0, "zero-byte allocation");
     size_t rb = round_block(bytes);
-    auto it = ctx->pool.find(rb);
     void *p = nullptr;
+    if (ctx->capturing) {
+        auto ci = ctx->cap_pool.find(rb);
+        if (ci != ctx->cap_pool.end() && !ci->second.empty()) {
+            p = ci->second.back();
+            ci->second.pop_back();
+            ctx->live[p] = rb;
+            *dptr = p;
+            return OFRI_OK;
+        }
+    }
+    auto it = ctx->pool.find(rb);
     if (it != ctx->pool.end() && !it->second.empty()) {
         p = it->second.back();
         it->second.pop_back();
@@ -112,6 +129,7 @@ extern "C" int ofri_alloc(ofri_ctx *ctx, size_t bytes, void **dptr) {
         }
     }
     ctx->live[p] = rb;
+    if (ctx->capturing) ctx->cap_blocks[p] = rb;
     *dptr = p;
     return OFRI_OK;
 }
@@ -123,8 +141,69 @@ extern "C" int ofri_free(ofri_ctx *ctx, void *dptr) {
     OFRI_REQUIRE(it != ctx->live.end(), "pointer %p was not allocated by this context", dptr);
     // stream-ordered reuse: every consumer of the pool enqueues on ctx->stream, so a block handed
     // out again is only touched after the work that last used it
-    ctx->pool[it->second].push_back(dptr);
+    if (ctx->capturing && ctx->cap_blocks.count(dptr)) ctx->cap_pool[it->second].push_back(dptr);
+    else ctx->pool[it->second].push_back(dptr);
     ctx->live.erase(it);
+    return OFRI_OK;
+}
+
+// ---- captured launch sequences ---------------------------------------------------------------------------
+extern "C" int ofri_graph_begin(ofri_ctx *ctx) {
+    OFRI_TRY(ofri_check_ctx(ctx));
+    OFRI_REQUIRE(!ctx->capturing, "a capture is already running on this context");
+    OFRI_REQUIRE(!ctx->prof, "switch the sweep timing off before capturing (ofri_prof_enable(ctx, 0))");
+    OFRI_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed));
+    ctx->capturing = true;
+    ctx->cap_pool.clear();
+    ctx->cap_blocks.clear();
+    return OFRI_OK;
+}
+
+extern "C" int ofri_graph_end(ofri_ctx *ctx, ofri_graph **out) {
+    OFRI_TRY(ofri_check_ctx(ctx));
+    OFRI_REQUIRE(out, "out is null");
+    *out = nullptr;
+    OFRI_REQUIRE(ctx->capturing, "no capture is running on this context");
+    ctx->capturing = false;
+    hipGraph_t g = nullptr;
+    const hipError_t e = hipStreamEndCapture(ctx->stream, &g);
+    // the blocks recycled inside the capture belong to the graph (or go back to the pool if there is none)
+    std::vector<std::pair<void *, size_t>> owned;
+    for (auto &kv : ctx->cap_pool)
+        for (void *p : kv.second) owned.push_back({p, kv.first});
+    ctx->cap_pool.clear();
+    ctx->cap_blocks.clear();
+    hipGraphExec_t exec = nullptr;
+    hipError_t e2 = hipSuccess;
+    if (e == hipSuccess && g) e2 = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
+    if (e != hipSuccess || !g || e2 != hipSuccess) {
+        if (g) (void)hipGraphDestroy(g);
+        for (auto &b : owned) ctx->pool[b.second].push_back(b.first);
+        (void)hipGetLastError();
+        return ofri_set_error(OFRI_EHIP, "stream capture failed: %s (a call that waits for the GPU or copies to pageable "
+                              "host memory cannot be captured)", hipGetErrorString(e != hipSuccess ? e : e2));
+    }
+    ofri_graph *gr = new ofri_graph();
+    gr->ctx = ctx; gr->graph = g; gr->exec = exec; gr->blocks = std::move(owned);
+    *out = gr;
+    return OFRI_OK;
+}
+
+extern "C" int ofri_graph_launch(ofri_ctx *ctx, ofri_graph *graph) {
+    OFRI_TRY(ofri_check_ctx(ctx));
+    OFRI_REQUIRE(graph && graph->ctx == ctx, "the graph was captured on another context");
+    OFRI_REQUIRE(!ctx->capturing, "a capture is running on this context");
+    OFRI_HIP(hipGraphLaunch(graph->exec, ctx->stream));
+    return OFRI_OK;
+}
+
+// the context must still exist; the graph's scratch memory goes back to its pool
+extern "C" int ofri_graph_destroy(ofri_graph *graph) {
+    if (!graph) return OFRI_OK;
+    (void)hipGraphExecDestroy(graph->exec);
+    (void)hipGraphDestroy(graph->graph);
+    for (auto &b : graph->blocks) graph->ctx->pool[b.second].push_back(b.first);
+    delete graph;
     return OFRI_OK;
 }
 
@@ -133,7 +212,7 @@ extern "C" int ofri_upload(ofri_ctx *ctx, void *dst, const void *src_host, size_
     OFRI_REQUIRE(dst && src_host, "null pointer");
     if (!bytes) return OFRI_OK;
     OFRI_HIP(hipMemcpyAsync(dst, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
-    OFRI_HIP(hipStreamSynchronize(ctx->stream));
+    OFRI_TRY(ofri_stream_wait(ctx));
     return OFRI_OK;
 }
 
@@ -142,7 +221,7 @@ extern "C" int ofri_download(ofri_ctx *ctx, void *dst_host, const void *src, siz
     OFRI_REQUIRE(dst_host && src, "null pointer");
     if (!bytes) return OFRI_OK;
     OFRI_HIP(hipMemcpyAsync(dst_host, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    OFRI_HIP(hipStreamSynchronize(ctx->stream));
+    OFRI_TRY(ofri_stream_wait(ctx));
     return OFRI_OK;
 }
 
@@ -163,6 +242,7 @@ extern "C" int ofri_zero(ofri_ctx *ctx, void *dst, size_t bytes) {
 }
 
 int ofri_upload_table(ofri_ctx *ctx, PoolBuf &buf, const void *host, size_t bytes) {
+    OFRI_REQUIRE(!ctx->capturing, "per-call host tables cannot be part of a captured sequence");
     OFRI_TRY(buf.get(bytes));
     OFRI_HIP(hipMemcpyAsync(buf.p, host, bytes, hipMemcpyHostToDevice, ctx->stream));
     return OFRI_OK;
@@ -171,6 +251,7 @@ int ofri_upload_table(ofri_ctx *ctx, PoolBuf &buf, const void *host, size_t byte
 int ofri_cached_table(ofri_ctx *ctx, const std::string &key, const void *host, size_t bytes, void **dptr) {
     void *p = ofri_find_table(ctx, key);
     if (!p) {
+        OFRI_REQUIRE(!ctx->capturing, "a constant table is missing: run the sequence once before capturing it");
         OFRI_HIP(hipMalloc(&p, bytes));
         hipError_t e = hipMemcpy(p, host, bytes, hipMemcpyHostToDevice);
         if (e != hipSuccess) { (void)hipFree(p); return ofri_set_error(OFRI_EHIP, "table upload: %s", hipGetErrorString(e)); }
@@ -370,7 +451,7 @@ int ofri_max_dev(ofri_ctx *ctx, const float *a, size_t n, int slot) {
 double *ofri_red_slot(ofri_ctx *ctx, int slot) { return ctx->red_partials + RED_BLOCKS + slot; }
 int ofri_read_slots(ofri_ctx *ctx, int first, int count, double *out_host) {
     OFRI_HIP(hipMemcpyAsync(ctx->pinned, ofri_red_slot(ctx, first), count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    OFRI_HIP(hipStreamSynchronize(ctx->stream));
+    OFRI_TRY(ofri_stream_wait(ctx));
     memcpy(out_host, ctx->pinned, count * sizeof(double));
     return OFRI_OK;
 }

@@ -26,6 +26,18 @@ struct ofri_ctx {
     bool prof = false;
     struct ProfRec { hipEvent_t a, b; int rows, cols, launches, sweeps; };
     std::vector<ProfRec> prof_recs;
+    // stream capture (ofri_graph_begin .. ofri_graph_end): blocks handed out while capturing are recycled among
+    // the captured work only and end up owned by the graph, so nothing else is ever given memory the graph writes
+    bool capturing = false;
+    std::map<size_t, std::vector<void *>> cap_pool;    // blocks freed again during the capture
+    std::map<void *, size_t> cap_blocks;               // every block handed out during the capture
+};
+
+struct ofri_graph {
+    ofri_ctx *ctx;
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+    std::vector<std::pair<void *, size_t>> blocks;     // scratch memory of the captured work
 };
 
 struct ofri_event {
@@ -34,6 +46,8 @@ struct ofri_event {
 };
 
 int ofri_set_error(int code, const char *fmt, ...);
+// host waits for the context's stream; refused while the stream is being captured into a graph
+int ofri_stream_wait(ofri_ctx *ctx);
 
 #define OFRI_HIP(call)                                                                     \
     do {                                                                                   \

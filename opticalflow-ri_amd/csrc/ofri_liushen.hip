@@ -241,7 +241,7 @@ extern "C" int ofri_ls_compute(ofri_ctx *ctx, const float *im1, const float *im2
     if (err_host || iters_host) {
         LsState hs;
         OFRI_HIP(hipMemcpyAsync(ctx->pinned, state, sizeof(LsState), hipMemcpyDeviceToHost, ctx->stream));
-        OFRI_HIP(hipStreamSynchronize(ctx->stream));
+        OFRI_TRY(ofri_stream_wait(ctx));
         memcpy(&hs, ctx->pinned, sizeof(LsState));
         if (err_host) *err_host = hs.iters ? hs.err : 0.0;
         if (iters_host) *iters_host = hs.iters;

@@ -74,7 +74,7 @@ extern "C" int ofri_warp_shift_ofe(ofri_ctx *ctx, const float *im, const float *
     OFRI_LAUNCH_CHECK();
     int bad[2];
     OFRI_HIP(hipMemcpyAsync(bad, oob.p, sizeof(bad), hipMemcpyDeviceToHost, ctx->stream));
-    OFRI_HIP(hipStreamSynchronize(ctx->stream));
+    OFRI_TRY(ofri_stream_wait(ctx));
     for (int axis = 0; axis < 2; ++axis) {
         if (bad[axis] == 0x7F7F7F7F) continue;
         // NumPy validates the row indices before the column indices and names the first offender

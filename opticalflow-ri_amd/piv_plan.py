@@ -1,0 +1,99 @@
+"""A frame-pair pipeline captured once and replayed: for streams of equally sized pairs.
+
+Below about 2048 x 2048 pixels the rate of ``genericPyramidalOpticalFlow`` is set by the host (one Python call
+and one kernel launch per step of the driver), not by the GPU.  ``FlowPlan`` runs the driver once while the
+context records its launches into a HIP graph, and every later pair costs two copies and one graph launch.  The
+reference has no counterpart (its driver is re-interpreted per pair, GenericPyramidalOpticalFlow.py:256-416);
+results are the same bits as ``genericPyramidalOpticalFlow`` with the same arguments.
+
+    plan = FlowPlan((1024, 1024), 3.4, lambda: HSOpticalFlowAlgoAdapter([21, 45], 100), pyramidalLevels=2)
+    for a, b in pairs:
+        U, V = plan(a, b)            # NumPy in, NumPy out
+"""
+import numpy as np
+
+import _ofri
+from GenericPyramidalOpticalFlow import pyramidal_flow_device
+
+
+class FlowPlan(object):
+    """``make_adapter``: a callable that returns a fresh main adapter (adapters consume their parameter lists, so
+    every run of the driver needs a new one).  Works for sequences that never wait for the GPU: Horn-Schunck and
+    Liu-Shen (whose stopping rule stays on the GPU) with the bilinear warp.  Sequences that read something back
+    (the biLinear=False warp's range check) or upload per-call host tables (Farneback, dense LK) raise OfriError
+    at construction."""
+
+    def __init__(self, shape, FILTER, make_adapter, pyramidalLevels=1, kLevels=1, FILTER_OPT=None, ctx=None, **driver_args):
+        self.ctx = ctx if ctx is not None else _ofri.context()
+        self.shape = (int(shape[0]), int(shape[1]))
+        self.im1, self.im2 = self.ctx.zeros(self.shape), self.ctx.zeros(self.shape)
+
+        def run():
+            return pyramidal_flow_device(self.im1, self.im2, FILTER, make_adapter(), int(pyramidalLevels), int(kLevels),
+                                         FILTER_OPT, **driver_args)
+
+        run()                               # builds the cached tables and fills the pool: the capture allocates nothing new
+        self.ctx.graph_begin()
+        try:
+            self.U, self.V = run()
+        except Exception:
+            try:
+                self.ctx.graph_end().close()
+            except _ofri.OfriError:
+                pass
+            raise
+        self.graph = self.ctx.graph_end()
+
+    def load(self, frame1, frame2):
+        """Put a pair into the plan's input arrays: NumPy arrays (uint8, uint16 or anything float32 holds) or
+        DeviceArrays of the plan's shape."""
+        for dst, src in ((self.im1, frame1), (self.im2, frame2)):
+            if isinstance(src, _ofri.DeviceArray):
+                if src.shape != self.shape or src.dtype != np.float32:
+                    raise ValueError("expected a float32 DeviceArray of shape %r" % (self.shape,))
+                _ofri.check(_ofri.lib().ofri_copy(self.ctx.handle, dst.ptr, src.ptr, dst.nbytes))
+            else:
+                self.ctx.upload_into(dst, src)
+
+    def run(self):
+        """Replay on the loaded pair; returns the plan's own (U, V) DeviceArrays, overwritten by the next run."""
+        self.graph.launch()
+        return self.U, self.V
+
+    def __call__(self, frame1, frame2):
+        self.load(frame1, frame2)
+        U, V = self.run()
+        return U.numpy(), V.numpy()
+
+    def close(self):
+        self.graph.close()
+
+
+class PlanPool(object):
+    """Several FlowPlans on contexts (streams) of their own, fed round-robin: small frames do not fill the GPU one
+    pair at a time (at 1024 x 1024 two pairs in flight give 1.8 times the rate of one).  ``flows(pairs)`` yields
+    (U, V) NumPy arrays in the order of the pairs."""
+
+    def __init__(self, shape, FILTER, make_adapter, in_flight=2, device=0, **plan_args):
+        self.plans = [FlowPlan(shape, FILTER, make_adapter, ctx=_ofri.Context(device), **plan_args)
+                      for _ in range(max(1, int(in_flight)))]
+
+    def flows(self, pairs):
+        busy = []                                     # plans whose result has not been collected, oldest first
+        free = list(self.plans)
+        for a, b in pairs:
+            if not free:
+                p = busy.pop(0)
+                yield p.U.numpy(), p.V.numpy()        # waits for that plan's stream only
+                free.append(p)
+            p = free.pop(0)
+            p.load(a, b)
+            p.run()
+            busy.append(p)
+        for p in busy:
+            yield p.U.numpy(), p.V.numpy()
+
+    def close(self):
+        for p in self.plans:
+            p.close()
+            p.ctx.close()

@@ -88,3 +88,80 @@ def test_driver_accepts_uint8_frames_like_float32_frames(pair):
     U2, V2 = genericPyramidalOpticalFlow(big[0].astype(np.float32), big[1].astype(np.float32), 3.4,
                                          HSOpticalFlowAlgoAdapter([21, 45], 20), 2, 1, None)
     assert U1.tobytes() == U2.tobytes() and V1.tobytes() == V2.tobytes()
+
+
+# ------------------------------------------------------------------------------ captured pipelines
+@pytest.mark.parametrize("shape,levels", [((256, 256), 2), ((200, 312), 1), ((2048, 2048), 2)])
+def test_flow_plan_replays_the_driver_bit_for_bit(shape, levels):
+    """FlowPlan (the driver's launches captured into a HIP graph) against genericPyramidalOpticalFlow on several
+    pairs in a row, with other allocations and work on the same context in between."""
+    import _ofri
+    from GenericPyramidalOpticalFlow import genericPyramidalOpticalFlow
+    from HornSchunck import HSOpticalFlowAlgoAdapter
+    from piv_plan import FlowPlan
+    from piv_synth import synth_piv
+    ctx = _ofri.context(0)
+    alphas = [21, 45][:levels]
+    plan = FlowPlan(shape, 3.4, lambda: HSOpticalFlowAlgoAdapter(list(alphas), 30), pyramidalLevels=levels)
+    rng = np.random.default_rng(7)
+    for seed in (1, 2, 3):
+        a, b = synth_piv(shape[0], shape[1], seed=seed)
+        # memory handed out after the capture must not be the graph's scratch: fill some and check it afterwards
+        guard_host = [rng.standard_normal(shape).astype(np.float32) for _ in range(4)]
+        guard = [ctx.upload(g) for g in guard_host]
+        U, V = plan(a, b)
+        Ur, Vr = genericPyramidalOpticalFlow(a.astype(np.float32), b.astype(np.float32), 3.4,
+                                             HSOpticalFlowAlgoAdapter(list(alphas), 30), levels, 1, None)
+        assert U.tobytes() == Ur.tobytes() and V.tobytes() == Vr.tobytes()
+        for g, h in zip(guard, guard_host):
+            assert g.numpy().tobytes() == h.tobytes()
+    plan.close()
+
+
+def test_flow_plan_with_liushen_refinement(pair):
+    """Liu-Shen keeps its stopping rule on the GPU, so Horn-Schunck + Liu-Shen (the reference's LiuSE examples) is
+    capturable too."""
+    from GenericPyramidalOpticalFlow import genericPyramidalOpticalFlow
+    from HornSchunck import HSOpticalFlowAlgoAdapter
+    from PhysicsBasedOpticalFlowLiuShen import LiuShenOpticalFlowAlgoAdapter
+    from piv_plan import FlowPlan
+    a, b = pair[0][:192, :256].copy(), pair[1][:192, :256].copy()
+    plan = FlowPlan(a.shape, 3.4, lambda: HSOpticalFlowAlgoAdapter([21, 45], 20), pyramidalLevels=2, FILTER_OPT=0.48,
+                    optionalOFlowAlgoAdapter=LiuShenOpticalFlowAlgoAdapter(5))
+    for _ in range(2):
+        U, V = plan(a, b)
+        Ur, Vr = genericPyramidalOpticalFlow(a.copy(), b.copy(), 3.4, HSOpticalFlowAlgoAdapter([21, 45], 20), 2, 1, 0.48,
+                                             LiuShenOpticalFlowAlgoAdapter(5))
+        assert U.tobytes() == Ur.tobytes() and V.tobytes() == Vr.tobytes()
+    plan.close()
+
+
+def test_flow_plan_refuses_sequences_that_wait_for_the_gpu():
+    """The optical-flow-equation warp (biLinear=False) reads its range check back on the host."""
+    import _ofri
+    from HornSchunck import HSOpticalFlowAlgoAdapter
+    from piv_plan import FlowPlan
+    with pytest.raises(_ofri.OfriError):
+        FlowPlan((64, 64), 3.4, lambda: HSOpticalFlowAlgoAdapter([21, 45], 10, False), pyramidalLevels=2, warping=True,
+                 biLinear=False)
+    # the context is usable afterwards
+    ctx = _ofri.context(0)
+    x = np.arange(12, dtype=np.float32).reshape(3, 4)
+    assert np.array_equal(ctx.upload(x).numpy(), x)
+
+
+def test_plan_pool_keeps_pair_order_and_bits():
+    from GenericPyramidalOpticalFlow import genericPyramidalOpticalFlow
+    from HornSchunck import HSOpticalFlowAlgoAdapter
+    from piv_plan import PlanPool
+    from piv_synth import synth_piv
+    shape = (160, 224)
+    pairs = [synth_piv(shape[0], shape[1], seed=s) for s in range(5)]
+    pool = PlanPool(shape, 3.4, lambda: HSOpticalFlowAlgoAdapter([21, 45], 20), in_flight=3, pyramidalLevels=2)
+    got = list(pool.flows(pairs))
+    pool.close()
+    assert len(got) == len(pairs)
+    for (a, b), (U, V) in zip(pairs, got):
+        Ur, Vr = genericPyramidalOpticalFlow(a.astype(np.float32), b.astype(np.float32), 3.4,
+                                             HSOpticalFlowAlgoAdapter([21, 45], 20), 2, 1, None)
+        assert U.tobytes() == Ur.tobytes() and V.tobytes() == Vr.tobytes()
