@@ -1,6 +1,6 @@
 // Temporally blocked Horn-Schunck: T Jacobi sweeps per launch on a register-resident tile.
 //
-// A 256-thread workgroup owns a region of FT_RX x FT_RY = 128 x 64 pixels (output tile 112 x 48 plus a
+// A 256-thread workgroup owns a region of 128 x 64 pixels (output tile 112 x 48 plus a
 // halo of 8).  Lane l of band b (one band = 32 lanes = 8 rows) keeps a column strip of 4 x 8 pixels of
 // U, V, fx, fy, ft and 1/den in registers.  Per sweep the left/right neighbours come from the adjacent
 // lanes (DPP wave shifts), the rows above/below the strip from a small double-buffered LDS array of band
@@ -13,11 +13,13 @@
 
 #define FT_HALO 8
 #define FT_RX 128
-#define FT_RY 64
 #define FT_OX (FT_RX - 2 * FT_HALO)
-#define FT_OY (FT_RY - 2 * FT_HALO)
-#define FT_S 8                       // rows per thread
-#define FT_BANDS (FT_RY / FT_S)      // 8 bands of 32 lanes
+#define FT_BANDS 8                   // bands of 32 lanes
+// Rows per thread are a template parameter FT_S: 8 (region 128 x 64, 112 x 48 stored) for fields that fill the GPU,
+// 4 (region 128 x 32, 112 x 16 stored) for small ones, where a launch has fewer workgroups than the GPU has CUs and
+// its duration is the latency of one workgroup: half the rows per thread is half that latency.
+#define FT_RY_OF(S) (FT_BANDS * (S))
+#define FT_OY_OF(S) (FT_RY_OF(S) - 2 * FT_HALO)
 
 // lane shifts with bound_ctrl: the wavefront's first / last lane reads 0 (a halo pixel, never stored)
 __device__ __forceinline__ float lane_left(float v) {    // value held by lane-1 (wave_shr:1)
@@ -37,7 +39,8 @@ __device__ __forceinline__ int refl101_any(int i, int n) {
 
 // One sweep of the workgroup's region, in place on the lane's strip; reads the band edge rows of buffer buf,
 // writes the new ones to buffer buf ^ 1.
-__device__ __forceinline__ void ft_sweep(float4 (&edge)[2][FT_BANDS + 2][2][2][32], float4 (&ftile)[FT_RY][32], int buf,
+template <int FT_S>
+__device__ __forceinline__ void ft_sweep(float4 (&edge)[2][FT_BANDS + 2][2][2][32], float4 (&ftile)[FT_RY_OF(FT_S)][32], int buf,
                                          int band, int l32, float (&cu)[FT_S][4], float (&cv)[FT_S][4],
                                          const float (&gx)[FT_S][4], const float (&gy)[FT_S][4], const float (&rd)[FT_S][4]) {
         float4 upU = edge[buf][band][1][0][l32], upV = edge[buf][band][1][1][l32];          // bottom row of the band above
@@ -85,12 +88,14 @@ __device__ __forceinline__ void ft_sweep(float4 (&edge)[2][FT_BANDS + 2][2][2][3
         __syncthreads();
 }
 
+template <int FT_S>
 __global__ void __launch_bounds__(256, 2)
 k_hs_fused(const float *__restrict__ U, const float *__restrict__ V, const float *__restrict__ fx,
            const float *__restrict__ fy, const float *__restrict__ ft, float *__restrict__ Un,
            float *__restrict__ Vn, float a2, int H, int W, int T, int tiles_x, int ntiles, int pin, int pc, int pout, int accumulate) {
     // [buffer][slot][top/bottom][U/V][lane]; slot b+1 belongs to band b, slots 0 and FT_BANDS+1 are never written
     __shared__ float4 edge[2][FT_BANDS + 2][2][2][32];
+    constexpr int FT_RY = FT_RY_OF(FT_S), FT_OY = FT_OY_OF(FT_S);
     __shared__ float4 ftile[FT_RY][32];          // ft of the region: read-only after the load, kept out of registers
     const int tid = threadIdx.x, l32 = tid & 31, band = tid >> 5;
 
@@ -150,10 +155,10 @@ k_hs_fused(const float *__restrict__ U, const float *__restrict__ V, const float
     // the loop's back edge without copies
     int s = 0;
     for (; s + 1 < T; s += 2) {
-        ft_sweep(edge, ftile, 0, band, l32, cu, cv, gx, gy, rd);
-        ft_sweep(edge, ftile, 1, band, l32, cu, cv, gx, gy, rd);
+        ft_sweep<FT_S>(edge, ftile, 0, band, l32, cu, cv, gx, gy, rd);
+        ft_sweep<FT_S>(edge, ftile, 1, band, l32, cu, cv, gx, gy, rd);
     }
-    if (s < T) ft_sweep(edge, ftile, 0, band, l32, cu, cv, gx, gy, rd);
+    if (s < T) ft_sweep<FT_S>(edge, ftile, 0, band, l32, cu, cv, gx, gy, rd);
 
     // store the inner tile: bands 1..FT_BANDS-2, strips 2..29, clipped to the image
     if (band >= FT_HALO / FT_S && band < FT_BANDS - FT_HALO / FT_S && l32 >= FT_HALO / 4 && l32 < 32 - FT_HALO / 4 && xin) {
@@ -189,8 +194,14 @@ int ofri_hs_fused_max_sweeps(void) { return FT_HALO; }
 int ofri_hs_fused_launch_pitched(ofri_ctx *ctx, const float *su, const float *sv, float *du, float *dv, const float *fx,
                                  const float *fy, const float *ft, float a2, int T, int H, int W, int pin, int pc, int pout,
                                  bool accumulate) {
-    const int tiles_x = ceil_div(W, FT_OX), tiles_y = ceil_div(H, FT_OY), ntiles = tiles_x * tiles_y;
-    k_hs_fused<<<ntiles, 256, 0, ctx->stream>>>(su, sv, fx, fy, ft, du, dv, a2, H, W, T, tiles_x, ntiles, pin, pc, pout, accumulate ? 1 : 0);
+    const int tiles_x = ceil_div(W, FT_OX);
+    int tiles_y = ceil_div(H, FT_OY_OF(8)), ntiles = tiles_x * tiles_y;
+    if (ntiles >= 2 * ofri_ctx_ncu(ctx)) {
+        k_hs_fused<8><<<ntiles, 256, 0, ctx->stream>>>(su, sv, fx, fy, ft, du, dv, a2, H, W, T, tiles_x, ntiles, pin, pc, pout, accumulate ? 1 : 0);
+    } else {        // too few workgroups to fill the GPU: shorter ones
+        tiles_y = ceil_div(H, FT_OY_OF(4)); ntiles = tiles_x * tiles_y;
+        k_hs_fused<4><<<ntiles, 256, 0, ctx->stream>>>(su, sv, fx, fy, ft, du, dv, a2, H, W, T, tiles_x, ntiles, pin, pc, pout, accumulate ? 1 : 0);
+    }
     OFRI_LAUNCH_CHECK();
     return OFRI_OK;
 }
