@@ -76,9 +76,9 @@ for r in tab:
 open(os.path.join(dst, tag + "_pmc_hbm_traffic.md"), "w").write("\n".join(lines) + "\n")
 traffic = {}
 for r in tab:
-    if r[0].startswith("k_hs_stream<true>"):
+    if r[0].startswith("k_hs_stream<12, true, false>"):
         traffic["k_hs_stream@" + r[2].split(" ")[0]] = r[6] * 1e6
-    if r[0] == "k_hs_fused":
+    if r[0].startswith("k_hs_fused<8>"):
         traffic["k_hs_fused@" + ("4096x4096" if int(r[1]) > 500000 else "2048x2048")] = r[6] * 1e6
 json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(traffic))
