@@ -32,16 +32,22 @@ __device__ __forceinline__ float lk_tree(float v, int lane) {
     return (s0 + s1) + (s2 + s3);
 }
 
-// CLK_FILTER_LINEAR | CLK_ADDRESS_CLAMP_TO_EDGE with unnormalised coordinates (OpenCL 1.2, 8.2)
-__device__ __forceinline__ float lk_sample(const float *__restrict__ J, int H, int W, float x, float y) {
-    float u = x - 0.5f, v = y - 0.5f;
-    float fu = floorf(u), fv = floorf(v);
-    float a = u - fu, b = v - fv;
-    int i0 = (int)fminf(fmaxf(fu, -2e9f), 2e9f), j0 = (int)fminf(fmaxf(fv, -2e9f), 2e9f);
-    int i1 = i0 + 1, j1 = j0 + 1;
-    i0 = clampi(i0, 0, W - 1); i1 = clampi(i1, 0, W - 1); j0 = clampi(j0, 0, H - 1); j1 = clampi(j1, 0, H - 1);
-    const float *r0 = J + (size_t)j0 * W, *r1 = J + (size_t)j1 * W;
-    return (((1.f - a) * (1.f - b)) * r0[i0] + (a * (1.f - b)) * r0[i1] + ((1.f - a) * b) * r1[i0]) + (a * b) * r1[i1];
+// CLK_FILTER_LINEAR | CLK_ADDRESS_CLAMP_TO_EDGE with unnormalised coordinates (OpenCL 1.2, 8.2), split by axis:
+// the two texel indices and the weight pair of a coordinate depend on that coordinate alone, and a lane's 4 x 4
+// samples share four x and four y coordinates.
+struct LkAxis { int i0, i1; float w0, w1; };      // texels and their weights (1 - frac, frac)
+__device__ __forceinline__ LkAxis lk_axis(float x, int n) {
+    const float u = x - 0.5f, fu = floorf(u), a = u - fu;
+    int i0 = (int)fminf(fmaxf(fu, -2e9f), 2e9f);
+    LkAxis r;
+    r.i1 = clampi(i0 + 1, 0, n - 1); r.i0 = clampi(i0, 0, n - 1);
+    r.w0 = 1.f - a; r.w1 = a;
+    return r;
+}
+// ((1-a)(1-b) t00 + a(1-b) t10 + (1-a)b t01) + ab t11, every product and sum rounded on its own
+__device__ __forceinline__ float lk_sample(const float *__restrict__ J, int W, const LkAxis &x, const LkAxis &y) {
+    const unsigned r0 = (unsigned)y.i0 * (unsigned)W, r1 = (unsigned)y.i1 * (unsigned)W;
+    return (((x.w0 * y.w0) * J[r0 + x.i0] + (x.w1 * y.w0) * J[r0 + x.i1]) + (x.w0 * y.w1) * J[r1 + x.i0]) + (x.w1 * y.w1) * J[r1 + x.i1];
 }
 
 __global__ void __launch_bounds__(64 * LK_PX)
@@ -119,11 +125,14 @@ k_lk_dense(const float *__restrict__ I, const float *__restrict__ J, const float
     for (int k = 0; k < p.iters; ++k) {
         if (ppx < -hx || ppx >= (float)W || ppy < -hy || ppy >= (float)H) break;
         float b1 = 0.f, b2 = 0.f;
+        LkAxis ax[4], ay[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { ax[t] = lk_axis(lx[t], W); ay[t] = lk_axis(ly[t], H); }
 #pragma unroll
         for (int ty = 0; ty < 4; ++ty)
 #pragma unroll
             for (int tx = 0; tx < 4; ++tx) {
-                float diff = (lk_sample(J, H, W, lx[tx], ly[ty]) - Ip[ty][tx]) * wgt[ty][tx];
+                float diff = (lk_sample(J, W, ax[tx], ay[ty]) - Ip[ty][tx]) * wgt[ty][tx];
                 b1 = fmaf(diff, Dx[ty][tx], b1);
                 b2 = fmaf(diff, Dy[ty][tx], b2);
             }
@@ -148,7 +157,7 @@ extern "C" int ofri_lk_compute(ofri_ctx *ctx, const float *im1, const float *im2
     OFRI_REQUIRE(im1 && im2 && U_in && V_in && U_out && V_out, "null pointer");
     OFRI_REQUIRE(rows > 0 && cols > 0 && niter >= 0, "bad shape or niter");
     OFRI_REQUIRE(half_window >= 0 && 2 * half_window + 1 <= 32, "window %d exceeds the 32-sample grid of the kernel", 2 * half_window + 1);
-    OFRI_REQUIRE(rows <= 65535, "too many rows for one launch");
+    OFRI_REQUIRE(rows <= 65535 && (long long)rows * cols < (1LL << 31), "field too large for one launch");
     LkParams p;
     p.win_x = p.win_y = 2 * half_window + 1;
     p.half_x = p.half_y = (p.win_x - 1) >> 1;
