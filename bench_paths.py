@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-path timings of the non-headline configurations (BASELINE.json configs 3-5 building blocks) on one
+"""Per-path timings of the non-headline configurations (Farneback, Liu-Shen, dense LK and their pyramids) on one
 GPU, with HIP events on the context's stream.  Complements bench.py (which measures the headline config).
 
     python bench_paths.py [--size 2048] [--reps 3]
