@@ -23,7 +23,7 @@
 #define SL_PF 6                          // rows the loader keeps in flight
 // The depth is a template parameter.  Built: NL = 12 sweeps per launch (three stage wavefronts + loader, 48 KB of LDS,
 // three workgroups per CU).  NL = 16 (four stage wavefronts + loader, 64 KB, two workgroups per CU) was measured at
-// 327 us per launch at 4096 x 4096 against 175 us for 12 sweeps: the lost workgroup costs more than the fourth SIMD gains.
+// 327 us per launch at 4096 x 4096 against 175 us for 12 sweeps: two workgroups per CU hide less of each other's waits.
 template <int NL> struct SlCfg {
     static constexpr int NS = NL / 2;                // pipeline stages (half-wavefronts)
     static constexpr int OX = SL_RX - 2 * NL;        // stored width: the sweeps eat NL columns on each side
