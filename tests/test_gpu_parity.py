@@ -302,7 +302,12 @@ def test_shift_warp_driver_vs_reference(ctx, pair):
 
 
 @pytest.mark.parametrize("shape_in,shape_out", [((4, 4), (9, 7)), ((5, 6), (10, 12)), ((4, 70), (8, 141)), ((33, 35), (67, 70)),
-                                                ((66, 67), (133, 131)), ((130, 40), (260, 83)), ((64, 64), (300, 100))])
+                                                ((66, 67), (133, 131)), ((130, 40), (260, 83)), ((64, 64), (300, 100)),
+                                                # around the column kernel's tiles (36 x 63 intervals), its row-weight window
+                                                # (96 fine rows) and its passes (24 fine rows): factors 2, 5 and below 1
+                                                ((37, 64), (74, 128)), ((38, 65), (76, 130)), ((73, 127), (146, 254)),
+                                                ((74, 128), (148, 256)), ((45, 70), (225, 77)), ((150, 200), (60, 500)),
+                                                ((200, 129), (401, 259))])
 def test_spline_upsample_small_and_ragged(ctx, shape_in, shape_out):
     """FITPACK's interpolating spline (RectBivariateSpline, reference :152-162) on sizes around the solver's
     chunk boundaries, the smallest legal grid, and factors other than 2."""
