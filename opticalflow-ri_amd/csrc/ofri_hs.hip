@@ -40,7 +40,8 @@ extern "C" int ofri_hs_derivs(ofri_ctx *ctx, const float *first, const float *se
 //   der  = (fx*ubar + fy*vbar + ft) / (alpha^2 + fx^2 + fy^2);  U = ubar - fx*der;  V = vbar - fy*der
 // EXACT = true follows scipy's float64 tap-by-tap accumulation and NumPy's unfused float32 element
 // ops, so the result is bit-identical to the reference; EXACT = false is float32 with a pinned
-// operation order (ofri_hs_math.h) and a reciprocal of the denominator instead of a division.
+// operation order (ofri_hs_math.h) on coefficients scaled once by 1/sqrt(alpha^2 + fx^2 + fy^2) instead of a
+// division per sweep; its kernels take the scaled planes A, B, C where the exact ones take fx, fy, ft.
 #define W6  0.16666667163372040   // float32(1/6)  as a double
 #define W12 0.08333333581686020   // float32(1/12) as a double
 
@@ -72,7 +73,7 @@ __device__ __forceinline__ void hs_point(float ua, float va, float fx, float fy,
         un = __fsub_rn(ua, __fmul_rn(fx, der));
         vn = __fsub_rn(va, __fmul_rn(fy, der));
     } else {
-        hs_update(ua, va, fx, fy, ft, hs_rden(fx, fy, a2), un, vn);
+        hs_update(ua, va, fx, fy, ft, un, vn);       // fx, fy, ft are the scaled coefficients A, B, C here
     }
 }
 
@@ -159,10 +160,10 @@ static int hs_sweep_launch(ofri_ctx *ctx, const float *U, const float *V, const 
 bool ofri_hs_fused_ok(const void *const *ptrs, int nptrs, int H, int W);
 int ofri_hs_fused_max_sweeps(void);
 int ofri_hs_fused_launch(ofri_ctx *ctx, const float *su, const float *sv, float *du, float *dv, const float *fx,
-                         const float *fy, const float *ft, float a2, int T, int H, int W);
+                         const float *fy, const float *ft, int T, int H, int W);
 
 int ofri_hs_fused_launch_pitched(ofri_ctx *ctx, const float *su, const float *sv, float *du, float *dv, const float *fx,
-                                 const float *fy, const float *ft, float a2, int T, int H, int W, int pin, int pc, int pout,
+                                 const float *fy, const float *ft, int T, int H, int W, int pin, int pc, int pout,
                                  bool accumulate);
 
 extern "C" int ofri_hs_set_fuse(ofri_ctx *ctx, int sweeps_per_launch) {
@@ -228,7 +229,7 @@ static int hs_stream_path(ofri_ctx *ctx, const float *Uin, const float *Vin, flo
             const int T = remaining < Tmax ? remaining : Tmax;
             const bool last = k == L - 1;
             OFRI_TRY(ofri_hs_fused_launch_pitched(ctx, set.U[cur], set.V[cur], last ? Uout : set.U[cur ^ 1], last ? Vout : set.V[cur ^ 1],
-                                                  set.fx, set.fy, set.ft, a2, T, rows, cols, set.P, set.P, last ? cols : set.P, last && accumulate));
+                                                  set.fx, set.fy, set.ft, T, rows, cols, set.P, set.P, last ? cols : set.P, last && accumulate));
             cur ^= 1;
             remaining -= T;
         }
@@ -239,8 +240,9 @@ static int hs_stream_path(ofri_ctx *ctx, const float *Uin, const float *Vin, flo
 
 // niter sweeps from (Uin, Vin) into (Uout, Vout); Uin/Vin may alias Uout/Vout.  Launches ping-pong between
 // the output planes and two pooled scratch planes, arranged so that the last launch lands in the output.
+// frames: (fx, fy) are the two images computeDerivatives takes and ft is a spare plane; the coefficients are made here.
 static int hs_iterate_io(ofri_ctx *ctx, const float *Uin, const float *Vin, float *Uout, float *Vout, const float *fx,
-                         const float *fy, const float *ft, float alpha, int niter, int rows, int cols) {
+                         const float *fy, const float *ft, float alpha, int niter, int rows, int cols, bool frames = false) {
     const size_t bytes = (size_t)rows * cols * sizeof(float);
     if (niter == 0) {
         if (Uin != Uout) OFRI_HIP(hipMemcpyAsync(Uout, Uin, bytes, hipMemcpyDeviceToDevice, ctx->stream));
@@ -249,15 +251,22 @@ static int hs_iterate_io(ofri_ctx *ctx, const float *Uin, const float *Vin, floa
     }
     const float a2 = alpha * alpha;         // alpha is a float32 in the reference's compiled signature
     const bool exact = ctx->hs_fuse == -1;  // -1: bit-exact restatement of scipy's float64 accumulation
-    {
+    if (!frames) {
         const void *q[7] = {Uin, Vin, Uout, Vout, fx, fy, ft};
         const int n_stream = hs_stream_share(ctx, q, 7, niter, rows, cols);
         if (n_stream > 0)
             return hs_stream_path(ctx, Uin, Vin, Uout, Vout, fx, fy, ft, nullptr, nullptr, a2, niter, n_stream, rows, cols);
     }
-    PoolBuf tu(ctx), tv(ctx);
+    PoolBuf tu(ctx), tv(ctx), ca(ctx), cb(ctx), cc(ctx);
     OFRI_TRY(tu.get(bytes));
     OFRI_TRY(tv.get(bytes));
+    OFRI_TRY(ca.get(bytes)); OFRI_TRY(cb.get(bytes)); OFRI_TRY(cc.get(bytes));
+    if (exact) {
+        if (frames) OFRI_TRY(ofri_hs_derivs(ctx, fx, fy, ca.as<float>(), cb.as<float>(), cc.as<float>(), rows, cols));
+    } else {                                 // the fast kernels work on the scaled coefficients
+        OFRI_TRY(ofri_hs_scaled_coefs(ctx, frames ? nullptr : fx, fy, ft, fx, fy, ca.as<float>(), cb.as<float>(), cc.as<float>(), a2, rows, cols));
+    }
+    if (frames || !exact) { fx = ca.as<float>(); fy = cb.as<float>(); ft = cc.as<float>(); }
     const void *ptrs[9] = {Uin, Vin, Uout, Vout, fx, fy, ft, tu.p, tv.p};
     const bool fused = !exact && ctx->hs_fuse != 1 && ofri_hs_fused_ok(ptrs, 9, rows, cols);
     int Tmax = 1;
@@ -278,7 +287,7 @@ static int hs_iterate_io(ofri_ctx *ctx, const float *Uin, const float *Vin, floa
         const bool to_out = detour ? ((L - k) % 2 == 0) : ((L - 1 - k) % 2 == 0);
         float *du = to_out ? Uout : tu.as<float>(), *dv = to_out ? Vout : tv.as<float>();
         const int T = remaining < Tmax ? remaining : Tmax;
-        if (fused) OFRI_TRY(ofri_hs_fused_launch(ctx, su, sv, du, dv, fx, fy, ft, a2, T, rows, cols));
+        if (fused) OFRI_TRY(ofri_hs_fused_launch(ctx, su, sv, du, dv, fx, fy, ft, T, rows, cols));
         else if (exact) OFRI_TRY(hs_sweep_launch<true>(ctx, su, sv, fx, fy, ft, du, dv, a2, rows, cols));
         else OFRI_TRY(hs_sweep_launch<false>(ctx, su, sv, fx, fy, ft, du, dv, a2, rows, cols));
         su = du; sv = dv;
@@ -325,10 +334,7 @@ extern "C" int ofri_hs_compute(ofri_ctx *ctx, const float *frame0, const float *
         OFRI_TRY(hs_stream_path(ctx, U_in, V_in, U_out, V_out, nullptr, nullptr, nullptr, frame1, frame0, alpha * alpha, niter,
                                 n_stream, rows, cols));
     } else {
-        PoolBuf fx(ctx), fy(ctx), ft(ctx);
-        OFRI_TRY(fx.get(bytes)); OFRI_TRY(fy.get(bytes)); OFRI_TRY(ft.get(bytes));
-        OFRI_TRY(ofri_hs_derivs(ctx, frame1, frame0, fx.as<float>(), fy.as<float>(), ft.as<float>(), rows, cols));
-        OFRI_TRY(hs_iterate_io(ctx, U_in, V_in, U_out, V_out, fx.as<float>(), fy.as<float>(), ft.as<float>(), alpha, niter, rows, cols));
+        OFRI_TRY(hs_iterate_io(ctx, U_in, V_in, U_out, V_out, frame1, frame0, nullptr, alpha, niter, rows, cols, true));
     }
     if (err_host) {
         OFRI_TRY(ofri_norm_diff_dev(ctx, U_out, U_in, n, 0));

@@ -2,7 +2,7 @@
 //
 // A 256-thread workgroup owns a region of 128 x 64 pixels (output tile 112 x 48 plus a
 // halo of 8).  Lane l of band b (one band = 32 lanes = 8 rows) keeps a column strip of 4 x 8 pixels of
-// U, V, fx, fy, ft and 1/den in registers.  Per sweep the left/right neighbours come from the adjacent
+// U, V and the scaled coefficients A, B (ofri_hs_math.h) in registers, C in LDS.  Per sweep the left/right neighbours come from the adjacent
 // lanes (DPP wave shifts), the rows above/below the strip from a small double-buffered LDS array of band
 // edge rows; one barrier per sweep.  Pixels within s of the region border are stale after s sweeps, which
 // is why only the inner 112 x 48 pixels are stored after T <= 8 sweeps.  Region pixels outside the image
@@ -42,7 +42,7 @@ __device__ __forceinline__ int refl101_any(int i, int n) {
 template <int FT_S>
 __device__ __forceinline__ void ft_sweep(float4 (&edge)[2][FT_BANDS + 2][2][2][32], float4 (&ftile)[FT_RY_OF(FT_S)][32], int buf,
                                          int band, int l32, float (&cu)[FT_S][4], float (&cv)[FT_S][4],
-                                         const float (&gx)[FT_S][4], const float (&gy)[FT_S][4], const float (&rd)[FT_S][4]) {
+                                         const float (&gx)[FT_S][4], const float (&gy)[FT_S][4]) {
         float4 upU = edge[buf][band][1][0][l32], upV = edge[buf][band][1][1][l32];          // bottom row of the band above
         float4 dnU = edge[buf][band + 2][0][0][l32], dnV = edge[buf][band + 2][0][1][l32];  // top row of the band below
         float pu[4] = {upU.x, upU.y, upU.z, upU.w}, pv[4] = {upV.x, upV.y, upV.z, upV.w};
@@ -76,7 +76,7 @@ __device__ __forceinline__ void ft_sweep(float4 (&edge)[2][FT_BANDS + 2][2][2][3
                 const int p = k == 3 ? k + 2 : k, q = k == 3 ? k : k + 2;
                 float ua = hs_avg(su[k], qu[p], qu[q]);
                 float va = hs_avg(sv[k], qv[p], qv[q]);
-                hs_update(ua, va, gx[r][k], gy[r][k], gt[k], rd[r][k], tu[k], tv[k]);
+                hs_update(ua, va, gx[r][k], gy[r][k], gt[k], tu[k], tv[k]);
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) { pu[k] = cu[r][k]; pv[k] = cv[r][k]; cu[r][k] = tu[k]; cv[r][k] = tv[k]; }
@@ -92,7 +92,7 @@ template <int FT_S>
 __global__ void __launch_bounds__(256, 2)
 k_hs_fused(const float *__restrict__ U, const float *__restrict__ V, const float *__restrict__ fx,
            const float *__restrict__ fy, const float *__restrict__ ft, float *__restrict__ Un,
-           float *__restrict__ Vn, float a2, int H, int W, int T, int tiles_x, int ntiles, int pin, int pc, int pout, int accumulate) {
+           float *__restrict__ Vn, int H, int W, int T, int tiles_x, int ntiles, int pin, int pc, int pout, int accumulate) {
     // [buffer][slot][top/bottom][U/V][lane]; slot b+1 belongs to band b, slots 0 and FT_BANDS+1 are never written
     __shared__ float4 edge[2][FT_BANDS + 2][2][2][32];
     constexpr int FT_RY = FT_RY_OF(FT_S), FT_OY = FT_OY_OF(FT_S);
@@ -108,7 +108,7 @@ k_hs_fused(const float *__restrict__ U, const float *__restrict__ V, const float
     const int gyb = ty * FT_OY - FT_HALO + band * FT_S;
     const bool xin = gx0 >= 0 && gx0 + 3 < W;
 
-    float cu[FT_S][4], cv[FT_S][4], gx[FT_S][4], gy[FT_S][4], rd[FT_S][4];
+    float cu[FT_S][4], cv[FT_S][4], gx[FT_S][4], gy[FT_S][4];
 #pragma unroll
     for (int r = 0; r < FT_S; ++r) {
         int y = gyb + r;
@@ -134,10 +134,6 @@ k_hs_fused(const float *__restrict__ U, const float *__restrict__ V, const float
             ftile[band * FT_S + r][l32] = make_float4(e[0], e[1], e[2], e[3]);
         }
     }
-#pragma unroll
-    for (int r = 0; r < FT_S; ++r)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) rd[r][k] = hs_rden(gx[r][k], gy[r][k], a2);
 
     if (tid < 64) {   // the two slots nobody owns: rows outside the region, never valid, keep them finite
         float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -155,10 +151,10 @@ k_hs_fused(const float *__restrict__ U, const float *__restrict__ V, const float
     // the loop's back edge without copies
     int s = 0;
     for (; s + 1 < T; s += 2) {
-        ft_sweep<FT_S>(edge, ftile, 0, band, l32, cu, cv, gx, gy, rd);
-        ft_sweep<FT_S>(edge, ftile, 1, band, l32, cu, cv, gx, gy, rd);
+        ft_sweep<FT_S>(edge, ftile, 0, band, l32, cu, cv, gx, gy);
+        ft_sweep<FT_S>(edge, ftile, 1, band, l32, cu, cv, gx, gy);
     }
-    if (s < T) ft_sweep<FT_S>(edge, ftile, 0, band, l32, cu, cv, gx, gy, rd);
+    if (s < T) ft_sweep<FT_S>(edge, ftile, 0, band, l32, cu, cv, gx, gy);
 
     // store the inner tile: bands 1..FT_BANDS-2, strips 2..29, clipped to the image
     if (band >= FT_HALO / FT_S && band < FT_BANDS - FT_HALO / FT_S && l32 >= FT_HALO / 4 && l32 < 32 - FT_HALO / 4 && xin) {
@@ -190,22 +186,22 @@ int ofri_hs_fused_max_sweeps(void) { return FT_HALO; }
 
 // One launch: T <= FT_HALO sweeps from (su, sv) into (du, dv); source and destination must differ.  Every
 // pointer is at pixel (0,0) of its plane; pin, pc, pout are the row pitches (in floats, multiples of 4) of the
-// source, coefficient and destination planes.  accumulate: the result is added to what (du, dv) hold.
+// source, coefficient and destination planes; fx, fy, ft hold the scaled coefficients A, B, C.  accumulate: the result is added to what (du, dv) hold.
 int ofri_hs_fused_launch_pitched(ofri_ctx *ctx, const float *su, const float *sv, float *du, float *dv, const float *fx,
-                                 const float *fy, const float *ft, float a2, int T, int H, int W, int pin, int pc, int pout,
+                                 const float *fy, const float *ft, int T, int H, int W, int pin, int pc, int pout,
                                  bool accumulate) {
     const int tiles_x = ceil_div(W, FT_OX);
     int tiles_y = ceil_div(H, FT_OY_OF(8)), ntiles = tiles_x * tiles_y;
     if (ntiles >= 2 * ofri_ctx_ncu(ctx)) {
-        k_hs_fused<8><<<ntiles, 256, 0, ctx->stream>>>(su, sv, fx, fy, ft, du, dv, a2, H, W, T, tiles_x, ntiles, pin, pc, pout, accumulate ? 1 : 0);
+        k_hs_fused<8><<<ntiles, 256, 0, ctx->stream>>>(su, sv, fx, fy, ft, du, dv, H, W, T, tiles_x, ntiles, pin, pc, pout, accumulate ? 1 : 0);
     } else {        // too few workgroups to fill the GPU: shorter ones
         tiles_y = ceil_div(H, FT_OY_OF(4)); ntiles = tiles_x * tiles_y;
-        k_hs_fused<4><<<ntiles, 256, 0, ctx->stream>>>(su, sv, fx, fy, ft, du, dv, a2, H, W, T, tiles_x, ntiles, pin, pc, pout, accumulate ? 1 : 0);
+        k_hs_fused<4><<<ntiles, 256, 0, ctx->stream>>>(su, sv, fx, fy, ft, du, dv, H, W, T, tiles_x, ntiles, pin, pc, pout, accumulate ? 1 : 0);
     }
     OFRI_LAUNCH_CHECK();
     return OFRI_OK;
 }
 int ofri_hs_fused_launch(ofri_ctx *ctx, const float *su, const float *sv, float *du, float *dv, const float *fx,
-                         const float *fy, const float *ft, float a2, int T, int H, int W) {
-    return ofri_hs_fused_launch_pitched(ctx, su, sv, du, dv, fx, fy, ft, a2, T, H, W, W, W, W, false);
+                         const float *fy, const float *ft, int T, int H, int W) {
+    return ofri_hs_fused_launch_pitched(ctx, su, sv, du, dv, fx, fy, ft, T, H, W, W, W, W, false);
 }

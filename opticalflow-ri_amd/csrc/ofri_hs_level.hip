@@ -3,7 +3,7 @@
 // separable Gaussian pre-filter (src/gaussian_filter.py:54-90) and the derivative cube (src/HornSchunck.py:107-127),
 // which the driver runs one after the other on whole images (:200-201, 374-375, 406).  A workgroup makes a
 // 64 x 32 tile: the warped images of the tile and its margins go to LDS, are filtered along rows, then along
-// columns, and differentiated; only fx, fy, ft and 1/(alpha^2 + fx^2 + fy^2) go to memory.  Every step uses the
+// columns, and differentiated; only the scaled coefficients A, B, C (hs_scaled) go to memory.  Every step uses the
 // arithmetic of the stand-alone kernels (ofri_image_math.h, ofri_hs_math.h), so the planes are the same bits.
 #include "ofri_hs_math.h"
 #include "ofri_hs_stream.h"
@@ -101,7 +101,7 @@ k_level_coefs(const float *__restrict__ first, const float *__restrict__ second,
         hs_derivs_of(ff[0][r0][c0], ff[0][r0][c1], ff[0][r1][c0], ff[0][r1][c1], ff[1][r0][c0], ff[1][r0][c1], ff[1][r1][c0],
                      ff[1][r1][c1], gx, gy, gt);
         const size_t s = (size_t)y * W + x;
-        o.fx[s] = gx; o.fy[s] = gy; o.ft[s] = gt; o.rd[s] = hs_rden(gx, gy, a2);
+        hs_scaled(gx, gy, gt, a2, o.fx[s], o.fy[s], o.ft[s]);
     }
 }
 

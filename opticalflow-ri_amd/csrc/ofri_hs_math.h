@@ -14,15 +14,19 @@ __device__ __forceinline__ float hs_q(float centre_row, float s) { return fmaf(2
 __device__ __forceinline__ float hs_avg(float s_centre, float q_a, float q_b) {
     return __fmul_rn(fmaf(2.0f, s_centre, __fadd_rn(q_a, q_b)), HS_W12F);
 }
-// 1 / (alpha^2 + fx^2 + fy^2), correctly rounded division
-__device__ __forceinline__ float hs_rden(float fx, float fy, float a2) {
-    return __fdiv_rn(1.0f, fmaf(fy, fy, fmaf(fx, fx, a2)));
+// The update u' = ubar - fx (fx ubar + fy vbar + ft) / den, den = alpha^2 + fx^2 + fy^2, in the fast kernels:
+// with the coefficients scaled once by s = sqrt(1/den),  A = fx s, B = fy s, C = ft s,
+//   u' = ubar - A (A ubar + B vbar + C),   v' = vbar - B (A ubar + B vbar + C),
+// four fused operations per pixel and three coefficients instead of five and four.  (The exact mode keeps the
+// reference's own sequence of operations, ofri_hs.hip.)
+__device__ __forceinline__ void hs_scaled(float fx, float fy, float ft, float a2, float &A, float &B, float &C) {
+    const float s = __fsqrt_rn(__fdiv_rn(1.0f, fmaf(fy, fy, fmaf(fx, fx, a2))));
+    A = __fmul_rn(fx, s); B = __fmul_rn(fy, s); C = __fmul_rn(ft, s);
 }
-__device__ __forceinline__ void hs_update(float ua, float va, float fx, float fy, float ft, float rden,
-                                          float &un, float &vn) {
-    float der = __fmul_rn(fmaf(fx, ua, fmaf(fy, va, ft)), rden);
-    un = fmaf(-fx, der, ua);
-    vn = fmaf(-fy, der, va);
+__device__ __forceinline__ void hs_update(float ua, float va, float A, float B, float C, float &un, float &vn) {
+    const float der = fmaf(A, ua, fmaf(B, va, C));
+    un = fmaf(-A, der, ua);
+    vn = fmaf(-B, der, va);
 }
 
 // The derivative cube at pixel (y, x) (reference computeDerivatives, src/HornSchunck.py:107-127).

@@ -1,12 +1,12 @@
-// Plane set of the Horn-Schunck row-streaming pipeline (ofri_hs_stream.hip): eight dense planes in one
-// allocation, in the order U0 V0 U1 V1 fx fy ft rd (the loader relies on V, fy, rd lying one plane after
-// U, fx, ft).  P is the row pitch in floats (= columns).
+// Plane set of the Horn-Schunck row-streaming pipeline (ofri_hs_stream.hip): seven dense planes in one
+// allocation, in the order U0 V0 U1 V1 A B C (the loader relies on V, B lying one plane after U, A).
+// A, B, C are the scaled coefficients of ofri_hs_math.h (hs_scaled).  P is the row pitch in floats (= columns).
 #pragma once
 #include "ofri_internal.h"
 
 struct OfriSlSet {
     float *U[2], *V[2];          // ping-pong pairs
-    float *fx, *fy, *ft, *rd;    // coefficients and 1/(alpha^2 + fx^2 + fy^2)
+    float *fx, *fy, *ft;         // scaled coefficients A, B, C
     int P;
     int zero_in;                 // pair 0 stands for a zero flow and holds nothing yet
 };
@@ -19,6 +19,10 @@ int ofri_sl_fill(ofri_ctx *ctx, OfriSlSet &s, const float *U, const float *V, co
                  const float *ft, const float *first, const float *second, float a2, int H, int W);
 int ofri_sl_sweeps(ofri_ctx *ctx, OfriSlSet &s, int n, bool to_dense, bool accumulate, float *Uout, float *Vout,
                    int H, int W, int *cur, int *launches);
+// Scaled coefficient planes (A, B, C) for the fast kernels outside a plane set: from dense fx, fy, ft, or
+// (fx == nullptr) differentiated from the two frames (first, second of computeDerivatives).  A, B, C may be fx, fy, ft.
+int ofri_hs_scaled_coefs(ofri_ctx *ctx, const float *fx, const float *fy, const float *ft, const float *first,
+                         const float *second, float *A, float *B, float *C, float a2, int H, int W);
 // the same from a pyramid level's images: warp (if U, V are given), pre-filter, derivatives in one pass
 bool ofri_sl_level_ok(int ntaps);
 int ofri_sl_fill_level(ofri_ctx *ctx, OfriSlSet &s, const float *first, const float *second, const float *U, const float *V,

@@ -4,9 +4,9 @@
 // walks down it one row per step.  Six half-wavefronts are six pipeline stages of two sweeps each: at
 // a step, stage s turns rows r-1, r, r+1 of its input into row r of sweep 2s+1 and, from that row and the
 // two it made in the steps before, row r-1 of sweep 2s+2, which it hands to stage s+1 through a two-slot
-// LDS ring.  The rows a stage works on stay in its registers; a row's fx, fy, ft and 1/den come from an
-// LDS ring once per stage and serve both of its sweeps.  A fourth wavefront streams the next rows from HBM
-// into the rings, six rows ahead.  One barrier per step; three workgroups (48 KB of LDS each) share a compute
+// LDS ring.  The rows a stage works on stay in its registers; a row's scaled coefficients A, B, C
+// (ofri_hs_math.h) come from an LDS ring once per stage and serve both of its sweeps.  A fourth wavefront streams the next rows from HBM
+// into the rings, six rows ahead.  One barrier per step; four workgroups (40 KB of LDS each) share a compute
 // unit.  Each input pixel is read once per 12 sweeps (times the strip overlap 128/104), which the tile kernel cannot reach:
 // its halo grows in both directions.
 //
@@ -21,8 +21,8 @@
 
 #define SL_RX 128                        // strip width (32 lanes x 4 pixels)
 #define SL_PF 6                          // rows the loader keeps in flight
-// The depth is a template parameter.  Built: NL = 12 sweeps per launch (three stage wavefronts + loader, 48 KB of LDS,
-// three workgroups per CU).  NL = 16 (four stage wavefronts + loader, 64 KB, two workgroups per CU) was measured at
+// The depth is a template parameter.  Built: NL = 12 sweeps per launch (three stage wavefronts + loader, 40 KB of LDS,
+// four workgroups per CU).  NL = 16 (four stage wavefronts + loader, 64 KB, two workgroups per CU) was measured at
 // 327 us per launch at 4096 x 4096 against 175 us for 12 sweeps: two workgroups per CU hide less of each other's waits.
 template <int NL> struct SlCfg {
     static constexpr int NS = NL / 2;                // pipeline stages (half-wavefronts)
@@ -30,7 +30,8 @@ template <int NL> struct SlCfg {
     static constexpr int LAG = 3 * NS;               // the last stage's second sweep runs this many rows behind the loader
     static constexpr int CR = LAG;                   // coefficient ring rows: rows rho-(LAG-1) .. rho are live
     static constexpr int THREADS = NS * 32 + 64;
-    static constexpr int PER_CU = NL == 12 ? 3 : 2;  // workgroups per CU that the LDS allows
+    static constexpr int PER_CU = NL == 12 ? 4 : 2;  // workgroups per CU that the LDS (40 KB each at NL = 12) and 128 registers allow
+    static constexpr int MIN_CHUNK = 128;            // chunk rows below which one workgroup per CU fewer is launched
 };
 #define SL_NL_MAIN 12
 
@@ -49,15 +50,15 @@ __device__ __forceinline__ int sl_refl(int i, int n) {
     return i < n ? i : p - i;
 }
 
-struct SlPlanes { const float *U, *V, *fx, *fy, *ft, *rd; };   // dense planes; V, fy, rd one plane after U, fx, ft
+struct SlPlanes { const float *U, *V, *fx, *fy, *ft; };        // dense planes (fx, fy, ft: scaled A, B, C); V, fy one plane after U, fx
 struct SlRow { float u[4], v[4]; };                            // a lane's four pixels of one row
-struct SlCoef { float4 fx, fy, ft, rd; };
+struct SlCoef { float4 fx, fy, ft; };
 
 // one sweep of a row: a = row above, c = the row, b = row below; pass (only when !FULL) = copy the row instead
 template <bool FULL>
 __device__ __forceinline__ SlRow sl_sweep(const SlRow &a, const SlRow &c, const SlRow &b, const SlCoef &g, bool pass) {
     const float gx[4] = {g.fx.x, g.fx.y, g.fx.z, g.fx.w}, gy[4] = {g.fy.x, g.fy.y, g.fy.z, g.fy.w};
-    const float gt[4] = {g.ft.x, g.ft.y, g.ft.z, g.ft.w}, rd[4] = {g.rd.x, g.rd.y, g.rd.z, g.rd.w};
+    const float gt[4] = {g.ft.x, g.ft.y, g.ft.z, g.ft.w};
     float su[4], sv[4], qu[6], qv[6];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -73,7 +74,7 @@ __device__ __forceinline__ SlRow sl_sweep(const SlRow &a, const SlRow &c, const 
         const int p = k == 3 ? k + 2 : k, q = k == 3 ? k : k + 2;
         float ua = hs_avg(su[k], qu[p], qu[q]);
         float va = hs_avg(sv[k], qv[p], qv[q]);
-        hs_update(ua, va, gx[k], gy[k], gt[k], rd[k], o.u[k], o.v[k]);
+        hs_update(ua, va, gx[k], gy[k], gt[k], o.u[k], o.v[k]);
         if (!FULL && pass) { o.u[k] = c.u[k]; o.v[k] = c.v[k]; }
     }
     return o;
@@ -92,14 +93,14 @@ struct SlStage {                 // registers of one pipeline stage (one lane)
 // destination holds; those values are fetched two steps (rows) ahead (row2: the row two below rowU, rowV is stored later).
 template <int NL, bool FULL, bool ACC>
 __device__ __forceinline__ void sl_stage_step(SlStage &st, float4 (&ring)[SlCfg<NL>::NS][2][2][32],
-                                              float4 (&coef)[SlCfg<NL>::CR][4][32], int stage, int l, bool passA, bool passB,
+                                              float4 (&coef)[SlCfg<NL>::CR][3][32], int stage, int l, bool passA, bool passB,
                                               bool store_lane, int lane_off, float *__restrict__ rowU, float *__restrict__ rowV,
                                               bool row_ok, long long row2, bool row2_ok) {
     constexpr int SL_NS = SlCfg<NL>::NS, SL_CR = SlCfg<NL>::CR;
     // newest input row rA+1, written one step ago
     const float4 nu4 = ring[stage][(st.rA + 1) & 1][0][l], nv4 = ring[stage][(st.rA + 1) & 1][1][l];
     SlCoef g;
-    g.fx = coef[st.cslot][0][l]; g.fy = coef[st.cslot][1][l]; g.ft = coef[st.cslot][2][l]; g.rd = coef[st.cslot][3][l];
+    g.fx = coef[st.cslot][0][l]; g.fy = coef[st.cslot][1][l]; g.ft = coef[st.cslot][2][l];
     st.cslot = st.cslot + 1 == SL_CR ? 0 : st.cslot + 1;
     SlRow nw;
     nw.u[0] = nu4.x; nw.u[1] = nu4.y; nw.u[2] = nu4.z; nw.u[3] = nu4.w;
@@ -151,13 +152,13 @@ __device__ __forceinline__ float4 sl_load4(const float *__restrict__ row, const 
     return make_float4(row[c.x0], row[c.x1], row[c.x2], row[c.x3]);
 }
 
-// The loader wavefront's loop.  Lanes 0-31 carry U, fx, ft; lanes 32-63 carry V, fy, 1/den (each one plane
+// The loader wavefront's loop.  Lanes 0-31 carry U, A, C; lanes 32-63 carry V, B (each one plane
 // after its partner, so the row address is a scalar base plus a per-lane offset).  Rows outside the image are
 // the reflected rows.  EDGE: the strip reaches over the left or right edge of the image.  ZERO: the flow is
 // zero on input and is not read.
 template <int NL, bool EDGE, bool ZERO>
 __device__ __forceinline__ void sl_loader(const SlPlanes &in, float4 (&ring)[SlCfg<NL>::NS][2][2][32],
-                                          float4 (&coef)[SlCfg<NL>::CR][4][32], int tid, int x0, int rho0, int NS, int H, int W) {
+                                          float4 (&coef)[SlCfg<NL>::CR][3][32], int tid, int x0, int rho0, int NS, int H, int W) {
     constexpr int SL_CR = SlCfg<NL>::CR;
     const int lj = tid & 31, lset = (tid >> 5) & 1;
     const int lx = x0 + 4 * lj;
@@ -172,11 +173,11 @@ __device__ __forceinline__ void sl_loader(const SlPlanes &in, float4 (&ring)[SlC
         const long long o = (long long)sl_refl((ROW_), H) * W;   /* scalar */                      \
         qa##U_ = ZERO ? make_float4(0.f, 0.f, 0.f, 0.f) : sl_load4<EDGE>(in.U + o + pl, cols);    \
         qb##U_ = sl_load4<EDGE>(in.fx + o + pl, cols);                                            \
-        qc##U_ = sl_load4<EDGE>(in.ft + o + pl, cols);                                            \
+        if (!lset) qc##U_ = sl_load4<EDGE>(in.ft + o, cols);                                      \
     }
     // the compiler must keep the first fill in program order (oldest load = first row consumed), or it has
     // to wait for every load in flight at the top of each round
-#define SL_Q(U_) float4 qa##U_, qb##U_, qc##U_; SL_LOAD(U_, rho0 + (U_)) asm volatile("" ::: "memory");
+#define SL_Q(U_) float4 qa##U_, qb##U_, qc##U_ = make_float4(0.f, 0.f, 0.f, 0.f); SL_LOAD(U_, rho0 + (U_)) asm volatile("" ::: "memory");
     SL_Q(0) SL_Q(1) SL_Q(2) SL_Q(3) SL_Q(4) SL_Q(5)
 #undef SL_Q
     static_assert(SL_PF == 6, "the prefetch registers are spelled out for six rows");
@@ -185,7 +186,7 @@ __device__ __forceinline__ void sl_loader(const SlPlanes &in, float4 (&ring)[SlC
         const int rho = rho0 + t0 + (U_);                                          \
         ring[0][rho & 1][lset][lj] = qa##U_;                                       \
         coef[lslot][lset][lj] = qb##U_;                                            \
-        coef[lslot][2 + lset][lj] = qc##U_;                                        \
+        if (!lset) coef[lslot][2][lj] = qc##U_;                                    \
         lslot = lslot + 1 == SL_CR ? 0 : lslot + 1;                                \
         SL_LOAD(U_, rho + SL_PF)                                                   \
         __syncthreads();                                                           \
@@ -206,7 +207,7 @@ k_hs_stream(SlPlanes in, float *__restrict__ Uo, float *__restrict__ Vo, int H, 
             int zero_in) {
     constexpr int SL_NS = SlCfg<NL>::NS, SL_CR = SlCfg<NL>::CR, SL_LAG = SlCfg<NL>::LAG, SL_OX = SlCfg<NL>::OX, SL_NL = NL;
     __shared__ float4 ring[SL_NS][2][2][32];      // ring[s]: input rows of stage s.  [row & 1][U|V][lane]
-    __shared__ float4 coef[SL_CR][4][32];         // [row slot][fx|fy|ft|1/den][lane]
+    __shared__ float4 coef[SL_CR][3][32];         // [row slot][A|B|C][lane]
     const int tid = threadIdx.x;
     // Workgroups go to the 8 XCDs round-robin by index, and each XCD has its own L2.  Renumber them so that an
     // XCD gets a run of neighbouring strips and chunks: the columns and fill rows that neighbours share are then
@@ -242,7 +243,7 @@ k_hs_stream(SlPlanes in, float *__restrict__ Uo, float *__restrict__ Vo, int H, 
             st.in0.u[k] = st.in0.v[k] = st.in1.u[k] = st.in1.v[k] = 0.f;
             st.mid0.u[k] = st.mid0.v[k] = st.mid1.u[k] = st.mid1.v[k] = 0.f;
         }
-        st.gprev.fx = st.gprev.fy = st.gprev.ft = st.gprev.rd = make_float4(0.f, 0.f, 0.f, 0.f);
+        st.gprev.fx = st.gprev.fy = st.gprev.ft = make_float4(0.f, 0.f, 0.f, 0.f);
         st.au0 = st.av0 = st.au1 = st.av1 = make_float4(0.f, 0.f, 0.f, 0.f);
         st.rA = rho0 - 2 - 3 * stage;
         st.cslot = (st.rA + 64 * SL_CR) % SL_CR;
@@ -263,10 +264,10 @@ k_hs_stream(SlPlanes in, float *__restrict__ Uo, float *__restrict__ Vo, int H, 
 }
 
 // ---- coefficient planes -------------------------------------------------------------------------------
-// fx, fy, ft and 1/(alpha^2 + fx^2 + fy^2) of a plane set.  FRAMES: differentiated on the spot from the two
-// frames (ca = first, cb = second image of computeDerivatives); otherwise ca, cb, cc are fx, fy, ft.
+// Scaled coefficients A, B, C (hs_scaled).  FRAMES: differentiated on the spot from the two frames (ca = first,
+// cb = second image of computeDerivatives); otherwise ca, cb, cc are fx, fy, ft (and may be the output planes).
 template <bool FRAMES>
-__global__ void k_sl_coefs(const float *__restrict__ ca, const float *__restrict__ cb, const float *__restrict__ cc, OfriSlSet o,
+__global__ void k_sl_coefs(const float *ca, const float *cb, const float *cc, float *oa, float *ob, float *oc,
                            int H, int W, float a2) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= W || y >= H) return;
@@ -274,18 +275,18 @@ __global__ void k_sl_coefs(const float *__restrict__ ca, const float *__restrict
     float gx, gy, gt;
     if (FRAMES) hs_derivs_at(ca, cb, y, x, H, W, gx, gy, gt);
     else { gx = ca[s]; gy = cb[s]; gt = cc[s]; }
-    o.fx[s] = gx; o.fy[s] = gy; o.ft[s] = gt; o.rd[s] = hs_rden(gx, gy, a2);
+    hs_scaled(gx, gy, gt, a2, oa[s], ob[s], oc[s]);
 }
 
 int ofri_hs_stream_sweeps(void) { return SL_NL_MAIN; }
 // worth it where the row chunks are long against the pipeline's fill (2048 x 2048 pixels and up)
 bool ofri_hs_stream_pays(int H, int W) { return (long long)H * W >= 4000000LL && (W & 3) == 0; }
 
-size_t ofri_sl_bytes(int H, int W) { return 8 * (size_t)H * W * sizeof(float); }
+size_t ofri_sl_bytes(int H, int W) { return 7 * (size_t)H * W * sizeof(float); }
 void ofri_sl_layout(float *base, int H, int W, OfriSlSet *s) {
     const size_t plane = (size_t)H * W;
     s->U[0] = base; s->V[0] = base + plane; s->U[1] = base + 2 * plane; s->V[1] = base + 3 * plane;
-    s->fx = base + 4 * plane; s->fy = base + 5 * plane; s->ft = base + 6 * plane; s->rd = base + 7 * plane;
+    s->fx = base + 4 * plane; s->fy = base + 5 * plane; s->ft = base + 6 * plane;
     s->P = W;
     s->zero_in = 0;
 }
@@ -299,18 +300,25 @@ int ofri_sl_fill(ofri_ctx *ctx, OfriSlSet &s, const float *U, const float *V, co
         OFRI_HIP(hipMemcpyAsync(s.U[0], U, bytes, hipMemcpyDeviceToDevice, ctx->stream));
         OFRI_HIP(hipMemcpyAsync(s.V[0], V, bytes, hipMemcpyDeviceToDevice, ctx->stream));
     }
+    return ofri_hs_scaled_coefs(ctx, fx, fy, ft, first, second, s.fx, s.fy, s.ft, a2, H, W);
+}
+int ofri_hs_scaled_coefs(ofri_ctx *ctx, const float *fx, const float *fy, const float *ft, const float *first,
+                         const float *second, float *A, float *B, float *C, float a2, int H, int W) {
     dim3 b(64, 4), g(ceil_div(W, 64), ceil_div(H, 4));
-    if (fx) k_sl_coefs<false><<<g, b, 0, ctx->stream>>>(fx, fy, ft, s, H, W, a2);
-    else k_sl_coefs<true><<<g, b, 0, ctx->stream>>>(first, second, nullptr, s, H, W, a2);
+    if (fx) k_sl_coefs<false><<<g, b, 0, ctx->stream>>>(fx, fy, ft, A, B, C, H, W, a2);
+    else k_sl_coefs<true><<<g, b, 0, ctx->stream>>>(first, second, nullptr, A, B, C, H, W, a2);
     OFRI_LAUNCH_CHECK();
     return OFRI_OK;
 }
 template <int NL>
 static void sl_launch(ofri_ctx *ctx, const SlPlanes &in, float *uo, float *vo, int H, int W, int T, int zero_in, bool acc) {
     const int tiles_x = ceil_div(W, SlCfg<NL>::OX);
-    // as many row chunks as fill the chip once with the workgroups per CU that the LDS allows
+    // As many row chunks as fill the chip once with the workgroups per CU that the LDS allows.  Every chunk pays
+    // NL + LAG rows of fill, so the last workgroup per CU is used only where the chunks stay long (4096 x 4096:
+    // 161 against 170 us per launch; 2048 x 2048: 71 against 66 us with it).
     int nchunks = SlCfg<NL>::PER_CU * ofri_ctx_ncu(ctx) / tiles_x;
     if (nchunks < 1) nchunks = 1;
+    if (ceil_div(H, nchunks) < SlCfg<NL>::MIN_CHUNK && SlCfg<NL>::PER_CU > 2) nchunks = max(1, (SlCfg<NL>::PER_CU - 1) * ofri_ctx_ncu(ctx) / tiles_x);
     const int chunk_rows = ceil_div(H, nchunks);
     nchunks = ceil_div(H, chunk_rows);
     const int grid = tiles_x * nchunks, thr = SlCfg<NL>::THREADS;
@@ -328,10 +336,10 @@ static void sl_launch(ofri_ctx *ctx, const SlPlanes &in, float *uo, float *vo, i
 // stays in the set and *cur names its pair.
 int ofri_sl_sweeps(ofri_ctx *ctx, OfriSlSet &s, int n, bool to_dense, bool accumulate, float *Uout, float *Vout,
                    int H, int W, int *cur, int *launches) {
-    // the loader addresses V, fy, rd as U, fx, ft plus one common plane stride
-    OFRI_REQUIRE(s.V[0] - s.U[0] == s.V[1] - s.U[1] && s.fy - s.fx == s.V[0] - s.U[0] && s.rd - s.ft == s.V[0] - s.U[0] &&
+    // the loader addresses V, B as U, A plus one common plane stride
+    OFRI_REQUIRE(s.V[0] - s.U[0] == s.V[1] - s.U[1] && s.fy - s.fx == s.V[0] - s.U[0] &&
                      s.V[0] > s.U[0] && (s.V[0] - s.U[0]) < (1LL << 29),
-                 "plane set is not laid out as U V U V fx fy ft rd");
+                 "plane set is not laid out as U V U V A B C");
     OFRI_REQUIRE((W & 3) == 0 && H >= 1 && W >= 4, "row-streaming pipeline needs a width that is a multiple of 4");
     OFRI_REQUIRE(to_dense || !accumulate, "only a dense destination can be accumulated into");
     const int L = ceil_div(n, SL_NL_MAIN);
@@ -339,7 +347,7 @@ int ofri_sl_sweeps(ofri_ctx *ctx, OfriSlSet &s, int n, bool to_dense, bool accum
     for (int k = 0; k < L; ++k) {
         const int T = remaining < SL_NL_MAIN ? remaining : SL_NL_MAIN;
         const bool dense = k == L - 1 && to_dense;
-        SlPlanes in{s.U[c], s.V[c], s.fx, s.fy, s.ft, s.rd};
+        SlPlanes in{s.U[c], s.V[c], s.fx, s.fy, s.ft};
         float *uo = dense ? Uout : s.U[c ^ 1], *vo = dense ? Vout : s.V[c ^ 1];
         sl_launch<SL_NL_MAIN>(ctx, in, uo, vo, H, W, T, s.zero_in, dense && accumulate);
         OFRI_LAUNCH_CHECK();
