@@ -14,7 +14,7 @@ double *ofri_red_slot(ofri_ctx *ctx, int slot);
 struct LsState {            // lives in device memory
     double err;             // total_error of the last executed iteration
     int iters;              // executed iterations
-    int done;               // stopping rule met
+    int done[2];            // stopping rule met; the check that runs inside launch k writes done[k & 1] (see k_ls_sweep)
 };
 
 // ---- set-up ------------------------------------------------------------------------------------
@@ -105,18 +105,53 @@ __device__ inline double ls_wave_sum(double v) {
     return v;
 }
 
-// One sweep.  A 64x4-thread workgroup owns a 64 x 16 pixel tile (4 rows per thread); the u/v tile with a
-// one-pixel apron is staged in LDS.  Blocks exit at once when the stopping rule has already been met.
+// total_error = (|du| + |dv|) / (rows*cols) of sweep k-1 from its per-workgroup partial sums; stop when it is <= tol
+// (reference loop: while err > tol and k < maxnum).  Run by one workgroup of 256 threads inside launch k.
+__device__ void ls_check(const double *__restrict__ partials, int nblocks, double inv_rc, double tol, LsState *state, int k) {
+    __shared__ double sm[2][4];
+    const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+    if (state->done[(k + 1) & 1]) {            // met before: hand the flag on
+        if (tid == 0) state->done[k & 1] = 1;
+        return;
+    }
+    double a = 0.0, b = 0.0;
+    const double2 *p2 = reinterpret_cast<const double2 *>(partials);
+    for (int i = tid; i < nblocks; i += 256) { double2 q = p2[i]; a += q.x; b += q.y; }
+    a = ls_wave_sum(a);
+    b = ls_wave_sum(b);
+    if ((tid & 63) == 0) { sm[0][tid >> 6] = a; sm[1][tid >> 6] = b; }
+    __syncthreads();
+    if (tid == 0) {
+        const double ta = (sm[0][0] + sm[0][1]) + (sm[0][2] + sm[0][3]), tb = (sm[1][0] + sm[1][1]) + (sm[1][2] + sm[1][3]);
+        const double err = (sqrt(ta) + sqrt(tb)) * inv_rc;
+        state->err = err;
+        state->iters += 1;
+        state->done[k & 1] = !(err > tol);
+    }
+}
+
+// Launch k = sweep k plus the stopping check of sweep k-1.  A 64x4-thread workgroup owns a 64 x 8 pixel tile (2 rows
+// per thread); the u/v tile with a one-pixel apron is staged in LDS.  Row 0 of the grid holds no tile: its first
+// workgroup runs the check of the sweep before (k > 0) while the tiles of this sweep are under way, so the check costs
+// no launch of its own.  Sweep k is therefore started without knowing whether sweep k-1 met the stopping rule: if it
+// did, this sweep's output (into the other buffer of the pair) is ignored, and the launches after it exit at once.
+// The tiles read the flag that the check inside the launch before wrote (done[(k-1) & 1]), never the one being
+// written in this launch.  A launch with a 1 x 1 grid is the check alone (after the last sweep).
 #define LS_TX 64
 #define LS_TY 8
 #define LS_RPT 2
 __global__ void __launch_bounds__(256)
 k_ls_sweep(const float *__restrict__ u, const float *__restrict__ v, float *__restrict__ un, float *__restrict__ vn,
-           LsFields f, float h, int H, int W, const LsState *__restrict__ state, double *__restrict__ partials) {
-    if (state->done) return;
+           LsFields f, float h, int H, int W, LsState *state, double *__restrict__ partials,
+           const double *__restrict__ partials_prev, int k, int nblocks, double inv_rc, double tol) {
+    if (blockIdx.y == 0) {
+        if (blockIdx.x == 0 && k > 0) ls_check(partials_prev, nblocks, inv_rc, tol, state, k);
+        return;
+    }
+    if (state->done[(k + 1) & 1]) return;
     __shared__ float su[LS_TY + 2][LS_TX + 2], sv[LS_TY + 2][LS_TX + 2];
     __shared__ double red[2][4];
-    const int bx = blockIdx.x * LS_TX, by = blockIdx.y * LS_TY;
+    const int bx = blockIdx.x * LS_TX, by = (blockIdx.y - 1) * LS_TY;
     const int tid = threadIdx.y * LS_TX + threadIdx.x;
     for (int i = tid; i < (LS_TY + 2) * (LS_TX + 2); i += 256) {
         int ly = i / (LS_TX + 2), lx = i - ly * (LS_TX + 2);
@@ -152,35 +187,13 @@ k_ls_sweep(const float *__restrict__ u, const float *__restrict__ v, float *__re
     if ((tid & 63) == 0) { red[0][tid >> 6] = du2; red[1][tid >> 6] = dv2; }
     __syncthreads();
     if (tid == 0) {
-        size_t bidx = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+        size_t bidx = (size_t)(blockIdx.y - 1) * gridDim.x + blockIdx.x;
         partials[2 * bidx] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
         partials[2 * bidx + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
     }
 }
 
-// total_error = (|du| + |dv|) / (rows*cols); stop when it is <= tol (reference loop: while err > tol and k < maxnum)
-__global__ void k_ls_check(const double *__restrict__ partials, int nblocks, double inv_rc, double tol, LsState *state) {
-    if (state->done) return;
-    __shared__ double sm[2][16];
-    double a = 0.0, b = 0.0;
-    const double2 *p2 = reinterpret_cast<const double2 *>(partials);
-    for (int i = threadIdx.x; i < nblocks; i += blockDim.x) { double2 q = p2[i]; a += q.x; b += q.y; }
-    a = ls_wave_sum(a);
-    b = ls_wave_sum(b);
-    if ((threadIdx.x & 63) == 0) { sm[0][threadIdx.x >> 6] = a; sm[1][threadIdx.x >> 6] = b; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double ta = 0.0, tb = 0.0;
-        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { ta += sm[0][w]; tb += sm[1][w]; }
-        double na = sqrt(ta), nb = sqrt(tb);
-        double err = (na + nb) * inv_rc;
-        state->err = err;
-        state->iters += 1;
-        if (!(err > tol)) state->done = 1;
-    }
-}
-
-__global__ void k_ls_init_state(LsState *s) { s->err = 1e8; s->iters = 0; s->done = 0; }
+__global__ void k_ls_init_state(LsState *s) { s->err = 1e8; s->iters = 0; s->done[0] = s->done[1] = 0; }
 
 // the result sits in buffer (iters & 1): 0 -> a, 1 -> b
 __global__ void k_ls_select(const float *__restrict__ a0, const float *__restrict__ a1, const float *__restrict__ b0,
@@ -205,7 +218,7 @@ extern "C" int ofri_ls_compute(ofri_ctx *ctx, const float *im1, const float *im2
     dim3 b(LS_TX, LS_TY / LS_RPT), g(ceil_div(cols, LS_TX), ceil_div(rows, LS_TY));
     const int nblocks = g.x * g.y;
     OFRI_TRY(st.get(sizeof(LsState)));
-    OFRI_TRY(parts.get((size_t)nblocks * 2 * sizeof(double)));
+    OFRI_TRY(parts.get((size_t)nblocks * 4 * sizeof(double)));     // two sets: a sweep writes one while the other is checked
     float *P = planes.as<float>();
     LsFields f{P, P + n, P + 2 * n, P + 3 * n, P + 4 * n, P + 5 * n, P + 6 * n, P + 7 * n};
     // im / max(im) per image
@@ -227,9 +240,13 @@ extern "C" int ofri_ls_compute(ofri_ctx *ctx, const float *im1, const float *im2
     for (int k = 0; k < maxit; ++k) {
         const float *su = (k & 1) ? b0 : a0, *sv = (k & 1) ? b1 : a1;
         float *du = (k & 1) ? a0 : b0, *dv = (k & 1) ? a1 : b1;
-        k_ls_sweep<<<g, b, 0, ctx->stream>>>(su, sv, du, dv, f, h, rows, cols, state, parts.as<double>());
+        double *pk = parts.as<double>() + (size_t)(k & 1) * 2 * nblocks, *pprev = parts.as<double>() + (size_t)((k + 1) & 1) * 2 * nblocks;
+        k_ls_sweep<<<dim3(g.x, g.y + 1), b, 0, ctx->stream>>>(su, sv, du, dv, f, h, rows, cols, state, pk, pprev, k, nblocks, inv_rc, tol);
         OFRI_LAUNCH_CHECK();
-        k_ls_check<<<1, 1024, 0, ctx->stream>>>(parts.as<double>(), nblocks, inv_rc, tol, state);
+    }
+    if (maxit > 0) {        // the check of the last sweep
+        const double *pprev = parts.as<double>() + (size_t)((maxit + 1) & 1) * 2 * nblocks;
+        k_ls_sweep<<<dim3(1, 1), b, 0, ctx->stream>>>(nullptr, nullptr, nullptr, nullptr, f, h, rows, cols, state, nullptr, pprev, maxit, nblocks, inv_rc, tol);
         OFRI_LAUNCH_CHECK();
     }
     {

@@ -22,7 +22,7 @@ dst = os.path.join(root, "profiles")
 
 
 def level_of(name, dur_ns):
-    # both pyramid levels launch k_hs_stream with the same grid (3 workgroups per CU); the full-resolution
+    # both pyramid levels launch k_hs_stream; the full-resolution
     # launches are the long ones
     if "k_hs_stream" in name:
         return "4096x4096 (duration > 120 us)" if dur_ns > 120000 else "2048x2048 (duration <= 120 us)"
