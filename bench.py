@@ -36,6 +36,8 @@ def parse():
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--same-device", action="store_true", help="all ranks compute on GPU 0 (rehearsal on a one-GPU box)")
+    ap.add_argument("--force-dist", action="store_true", help="take the multi-rank code path (process group, gather stream, "
+                    "barriers) even with one rank: rehearsal of the N > 1 path on a one-GPU box")
     ap.add_argument("--with-transfer", action="store_true", help="also report the rate including H2D/D2H copies")
     ap.add_argument("--graph", action="store_true", help="replay the pair's launches from a captured HIP graph (piv_plan.FlowPlan)")
     ap.add_argument("--in-flight", type=int, default=1, help="with --graph: pairs per step, each on its own context/stream "
@@ -67,7 +69,8 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     dist = torch = None
-    if world > 1:
+    multi = world > 1 or args.force_dist
+    if multi:
         import torch
         import torch.distributed as dist
         if args.backend == "nccl":
@@ -82,7 +85,7 @@ def main():
     H = W = args.size
     dev = 0 if args.same_device else local        # --same-device: rehearse several ranks on a one-GPU box
     stream = None
-    if world > 1 and args.backend == "nccl":
+    if multi and args.backend == "nccl":
         stream = torch.cuda.Stream(device=dev)
         torch.cuda.set_stream(stream)
         ctx = _ofri.Context(dev, stream.cuda_stream)
@@ -101,7 +104,7 @@ def main():
 
     # Every pair's flow field goes to rank 0 (the only exchange of the job).  The gather of pair i runs
     # on a side stream while pair i+1 is computed; two send buffers alternate.
-    gather = world > 1 and not args.no_gather
+    gather = multi and not args.no_gather
     gather_note = "none"
     pending = []
     if gather:
@@ -153,13 +156,13 @@ def main():
     def fence():
         while pending:
             pending.pop(0).wait()
-        if world > 1 and args.backend == "nccl":
+        if multi and args.backend == "nccl":
             if gather:
                 torch.cuda.current_stream().wait_stream(comm_stream)
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
-        elif world > 1:
+        elif multi:
             ctx.sync()
             dist.barrier()
         else:
@@ -179,7 +182,7 @@ def main():
     recs = ctx.prof_records()
     ctx.prof_enable(False)
 
-    if world > 1:
+    if multi:
         from piv_batch import max_over_ranks
         dt = max_over_ranks(dt, device="cuda" if args.backend == "nccl" else None)
 
@@ -243,7 +246,7 @@ def main():
         result["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -2,7 +2,7 @@
 """Per-path timings of the non-headline configurations (Farneback, Liu-Shen, dense LK and their pyramids) on one
 GPU, with HIP events on the context's stream.  Complements bench.py (which measures the headline config).
 
-    python bench_paths.py [--size 2048] [--reps 3]
+    python bench_paths.py [--size 2048] [--reps 3] [--cfg3-size 4096]
 Prints one JSON line per path: {"path", "size", "ms", "mpix_s", "alg_bytes_per_px", "gbs", "frac_hbm"}.
 """
 import argparse
@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--size", type=int, default=2048)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--lk-size", type=int, default=1024)
+    ap.add_argument("--cfg3-size", type=int, default=4096, help="also time the 2-level Farneback pyramid at this size (0: skip)")
     a = ap.parse_args()
     import _ofri
     from piv_synth import synth_piv
@@ -61,6 +62,13 @@ def main():
     report("farneback_compute_1_level", n, ms, 5 * 28 + 5 * 68 + 2 * 24 + 2 * 8 + 2 * 8)
     ms = timed(lambda: pyramidal_flow_device(im0, im1, 0.0, Farneback_PyCL(), 2, 1, None), a.reps)
     report("cfg3_farneback_2_level_pyramid", n, ms)
+    if a.cfg3_size and a.cfg3_size != n:      # the size the Farneback configuration is named on
+        m = a.cfg3_size
+        g0, g1 = synth_piv(m, m, seed=0)
+        k0, k1 = ctx.upload(g0.astype(np.float32)), ctx.upload(g1.astype(np.float32))
+        ms = timed(lambda: pyramidal_flow_device(k0, k1, 0.0, Farneback_PyCL(), 2, 1, None), a.reps)
+        report("cfg3_farneback_2_level_pyramid", m, ms)
+        del k0, k1
     ms = timed(lambda: pyramidal_flow_device(im0, im1, 0.0, Farneback_PyCL(), 2, 1, 0.48, LiuShenOpticalFlowAlgoAdapter(10)), a.reps)
     report("cfg4_farneback_plus_liushen_2_level", n, ms)
     ms = timed(lambda: pyramidal_flow_device(im0, im1, 3.4, HSOpticalFlowAlgoAdapter([21, 45], 100), 2, 1, 0.48,
