@@ -162,52 +162,58 @@ k_fb_window(const float *__restrict__ src, float *__restrict__ dst, float *__res
 }
 
 // Same filter for the reference's default window (ksize_half = 16, windowSize 33), with register
-// windows: the vertical pass gives each thread 4 stacked outputs of one column (36 LDS reads for 4
-// results instead of 132), the horizontal pass 4 adjacent outputs of one row fetched as nine 16-byte LDS
-// reads.  Taps are applied in the reference's order (centre, then pairs outward), so results are
-// identical to k_fb_window.
+// windows: a workgroup makes a 64 x 32 tile; the vertical pass gives each thread 4 stacked outputs of one
+// column (36 LDS reads for 4 results instead of 132), three such columns per thread (8 row groups x 96 columns
+// over 256 threads: every wavefront does the same work), the horizontal pass 4 adjacent outputs of one row
+// fetched as nine 16-byte LDS reads, two rows per thread.  Taps are applied in the reference's order (centre,
+// then pairs outward), so results are identical to k_fb_window.
+#define BW_TY 32
 template <int NP, int MODE, bool FLOW>
 __global__ void __launch_bounds__(256)
 k_fb_window16(const float *__restrict__ src, float *__restrict__ dst, float *__restrict__ flowx, float *__restrict__ flowy,
               int H, int W, FbTaps taps) {
-    constexpr int KSH = 16, TW = BL_TX + 2 * KSH, TH = BL_TY + 2 * KSH;      // 96 x 48
+    constexpr int KSH = 16, TW = BL_TX + 2 * KSH, TH = BW_TY + 2 * KSH;      // 96 x 64
+    constexpr int NLD = TH / 8 * 3;                                          // loads per thread and plane
+    constexpr int NR = BW_TY / 16;                                           // output rows per thread
     __shared__ float tin[TH][TW];
-    __shared__ __attribute__((aligned(16))) float tv[BL_TY][TW];
-    const int bx = blockIdx.x * BL_TX, by = blockIdx.y * BL_TY, tid = threadIdx.x;
+    __shared__ __attribute__((aligned(16))) float tv[BW_TY][TW];
+    const int bx = blockIdx.x * BL_TX, by = blockIdx.y * BW_TY, tid = threadIdx.x;
     const size_t P = (size_t)H * W;
-    const int ly = tid >> 4, xg = tid & 15;                                  // horizontal pass: row, group of 4 columns
-    float res[NP][4];
-    // this thread's 18 samples of a plane's 48 x 96 source tile: rows (tid>>5) + 8s, columns (tid&31) + 32q.
+    const int ly = tid >> 4, xg = tid & 15;                                  // horizontal pass: row (and row + 16), group of 4 columns
+    float res[NP][NR][4];
+    // this thread's samples of a plane's 64 x 96 source tile: rows (tid>>5) + 8s, columns (tid&31) + 32q.
     // All loads of a plane are issued together, and the next plane's are issued before the current
     // plane is filtered, so their latency hides behind the arithmetic.
-    unsigned offs[18];          // the launcher guarantees rows*cols < 2^32
+    unsigned roff[TH / 8], coff[3];     // row and column parts of the offsets; the launcher guarantees rows*cols < 2^32
 #pragma unroll
-    for (int sidx = 0; sidx < 6; ++sidx) {
+    for (int sidx = 0; sidx < TH / 8; ++sidx) {
         int y = by + (tid >> 5) + 8 * sidx - KSH;
         y = MODE == 0 ? fb_idx(y, H - 1) : clampi(y, 0, H - 1);
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            int x = bx + (tid & 31) + 32 * q - KSH;
-            x = MODE == 0 ? fb_idx(x, W - 1) : clampi(x, 0, W - 1);
-            offs[sidx * 3 + q] = (unsigned)y * (unsigned)W + (unsigned)x;
-        }
+        roff[sidx] = (unsigned)y * (unsigned)W;
     }
-    float pre[18];
 #pragma unroll
-    for (int e = 0; e < 18; ++e) pre[e] = src[offs[e]];
+    for (int q = 0; q < 3; ++q) {
+        int x = bx + (tid & 31) + 32 * q - KSH;
+        coff[q] = (unsigned)(MODE == 0 ? fb_idx(x, W - 1) : clampi(x, 0, W - 1));
+    }
+    float pre[NLD];
+#pragma unroll
+    for (int e = 0; e < NLD; ++e) pre[e] = src[roff[e / 3] + coff[e % 3]];
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
 #pragma unroll
-        for (int sidx = 0; sidx < 6; ++sidx)
+        for (int sidx = 0; sidx < TH / 8; ++sidx)
 #pragma unroll
             for (int q = 0; q < 3; ++q) tin[(tid >> 5) + 8 * sidx][(tid & 31) + 32 * q] = pre[sidx * 3 + q];
         __syncthreads();
         if (p + 1 < NP) {
             const float *sp = src + (size_t)(p + 1) * P;
 #pragma unroll
-            for (int e = 0; e < 18; ++e) pre[e] = sp[offs[e]];
+            for (int e = 0; e < NLD; ++e) pre[e] = sp[roff[e / 3] + coff[e % 3]];
         }
-        for (int i = tid; i < (BL_TY / 4) * TW; i += 256) {
+        static_assert((BW_TY / 4) * TW % 256 == 0, "the vertical pass divides evenly over the workgroup");
+#pragma unroll 1
+        for (int i = tid; i < (BW_TY / 4) * TW; i += 256) {
             const int rg = i / TW, col = i - rg * TW;
             float w[36];
 #pragma unroll
@@ -224,9 +230,11 @@ k_fb_window16(const float *__restrict__ src, float *__restrict__ dst, float *__r
             }
         }
         __syncthreads();
-        {
+#pragma unroll 1
+        for (int h = 0; h < NR; ++h) {
+            asm volatile("" ::: "memory");      // one row's window at a time in registers
             float c[36];
-            const float4 *row4 = reinterpret_cast<const float4 *>(&tv[ly][4 * xg]);
+            const float4 *row4 = reinterpret_cast<const float4 *>(&tv[ly + 16 * h][4 * xg]);
 #pragma unroll
             for (int q = 0; q < 9; ++q) { float4 v = row4[q]; c[4 * q] = v.x; c[4 * q + 1] = v.y; c[4 * q + 2] = v.z; c[4 * q + 3] = v.w; }
 #pragma unroll
@@ -237,30 +245,34 @@ k_fb_window16(const float *__restrict__ src, float *__restrict__ dst, float *__r
                     float sm = c[KSH + k - i] + c[KSH + k + i];
                     acc += MODE == 0 ? sm * taps.k[i] : sm;
                 }
-                res[p][k] = acc;
+                res[p][h][k] = acc;
             }
         }
         // next plane: tin is rewritten before, tv after the barrier that follows the tin load
     }
     const float box_inv = 1.f / ((1 + 2 * KSH) * (1 + 2 * KSH));
-    const int y = by + ly, x0 = bx + 4 * xg;
-    if (y >= H) return;
+    const int x0 = bx + 4 * xg;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        int x = x0 + k;
-        if (x >= W) continue;
-        size_t o = (size_t)y * W + x;
-        float v[NP];
+    for (int h = 0; h < NR; ++h) {
+        const int y = by + ly + 16 * h;
+        if (y >= H) continue;
 #pragma unroll
-        for (int p = 0; p < NP; ++p) v[p] = MODE == 0 ? res[p][k] : res[p][k] * box_inv;
-        if (FLOW) {
-            float g11 = v[0], g12 = v[NP > 1 ? 1 : 0], g22 = v[NP > 2 ? 2 : 0], h1 = v[NP > 3 ? 3 : 0], h2 = v[NP > 4 ? 4 : 0];
-            float detInv = 1.f / (g11 * g22 - g12 * g12 + 1e-3f);
-            flowx[o] = (g11 * h2 - g12 * h1) * detInv;
-            flowy[o] = (g22 * h1 - g12 * h2) * detInv;
-        } else {
+        for (int k = 0; k < 4; ++k) {
+            int x = x0 + k;
+            if (x >= W) continue;
+            size_t o = (size_t)y * W + x;
+            float v[NP];
 #pragma unroll
-            for (int p = 0; p < NP; ++p) dst[p * P + o] = v[p];
+            for (int p = 0; p < NP; ++p) v[p] = MODE == 0 ? res[p][h][k] : res[p][h][k] * box_inv;
+            if (FLOW) {
+                float g11 = v[0], g12 = v[NP > 1 ? 1 : 0], g22 = v[NP > 2 ? 2 : 0], h1 = v[NP > 3 ? 3 : 0], h2 = v[NP > 4 ? 4 : 0];
+                float detInv = 1.f / (g11 * g22 - g12 * g12 + 1e-3f);
+                flowx[o] = (g11 * h2 - g12 * h1) * detInv;
+                flowy[o] = (g22 * h1 - g12 * h2) * detInv;
+            } else {
+#pragma unroll
+                for (int p = 0; p < NP; ++p) dst[p * P + o] = v[p];
+            }
         }
     }
 }
@@ -278,7 +290,7 @@ static int fb_window_launch(ofri_ctx *ctx, const float *src, float *dst, float *
     memset(&t, 0, sizeof(t));
     if (MODE == 0) memcpy(t.k, taps_host, (ksh + 1) * sizeof(float));
     if (ksh == 16 && (size_t)rows * cols < 0xffffffffull) {
-        dim3 g16(ceil_div(cols, BL_TX), ceil_div(rows, BL_TY));
+        dim3 g16(ceil_div(cols, BL_TX), ceil_div(rows, BW_TY));
         k_fb_window16<NP, MODE, FLOW><<<g16, 256, 0, ctx->stream>>>(src, dst, fx, fy, rows, cols, t);
         OFRI_LAUNCH_CHECK();
         return OFRI_OK;
