@@ -35,19 +35,24 @@ __device__ __forceinline__ float lk_tree(float v, int lane) {
 // CLK_FILTER_LINEAR | CLK_ADDRESS_CLAMP_TO_EDGE with unnormalised coordinates (OpenCL 1.2, 8.2), split by axis:
 // the two texel indices and the weight pair of a coordinate depend on that coordinate alone, and a lane's 4 x 4
 // samples share four x and four y coordinates.
-struct LkAxis { int i0, i1; float w0, w1; };      // texels and their weights (1 - frac, frac)
-__device__ __forceinline__ LkAxis lk_axis(float x, int n) {
+// i0, i1 are byte offsets: texel index times `scale` (4 along a row, 4 * W from row to row), so that a sample's address
+// is the image base (uniform, held in scalar registers) plus one 32-bit sum.
+struct LkAxis { unsigned i0, i1; float w0, w1; };      // texels and their weights (1 - frac, frac)
+__device__ __forceinline__ LkAxis lk_axis(float x, int n, unsigned scale) {
     const float u = x - 0.5f, fu = floorf(u), a = u - fu;
     int i0 = (int)fminf(fmaxf(fu, -2e9f), 2e9f);
     LkAxis r;
-    r.i1 = clampi(i0 + 1, 0, n - 1); r.i0 = clampi(i0, 0, n - 1);
+    r.i1 = (unsigned)clampi(i0 + 1, 0, n - 1) * scale; r.i0 = (unsigned)clampi(i0, 0, n - 1) * scale;
     r.w0 = 1.f - a; r.w1 = a;
     return r;
 }
+__device__ __forceinline__ float lk_at(const float *__restrict__ J, unsigned byte_off) {
+    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(J) + byte_off);
+}
 // ((1-a)(1-b) t00 + a(1-b) t10 + (1-a)b t01) + ab t11, every product and sum rounded on its own
-__device__ __forceinline__ float lk_sample(const float *__restrict__ J, int W, const LkAxis &x, const LkAxis &y) {
-    const unsigned r0 = (unsigned)y.i0 * (unsigned)W, r1 = (unsigned)y.i1 * (unsigned)W;
-    return (((x.w0 * y.w0) * J[r0 + x.i0] + (x.w1 * y.w0) * J[r0 + x.i1]) + (x.w0 * y.w1) * J[r1 + x.i0]) + (x.w1 * y.w1) * J[r1 + x.i1];
+__device__ __forceinline__ float lk_sample(const float *__restrict__ J, const LkAxis &x, const LkAxis &y) {
+    return (((x.w0 * y.w0) * lk_at(J, y.i0 + x.i0) + (x.w1 * y.w0) * lk_at(J, y.i0 + x.i1)) + (x.w0 * y.w1) * lk_at(J, y.i1 + x.i0)) +
+           (x.w1 * y.w1) * lk_at(J, y.i1 + x.i1);
 }
 
 __global__ void __launch_bounds__(64 * LK_PX)
@@ -127,12 +132,12 @@ k_lk_dense(const float *__restrict__ I, const float *__restrict__ J, const float
         float b1 = 0.f, b2 = 0.f;
         LkAxis ax[4], ay[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) { ax[t] = lk_axis(lx[t], W); ay[t] = lk_axis(ly[t], H); }
+        for (int t = 0; t < 4; ++t) { ax[t] = lk_axis(lx[t], W, 4u); ay[t] = lk_axis(ly[t], H, 4u * (unsigned)W); }
 #pragma unroll
         for (int ty = 0; ty < 4; ++ty)
 #pragma unroll
             for (int tx = 0; tx < 4; ++tx) {
-                float diff = (lk_sample(J, W, ax[tx], ay[ty]) - Ip[ty][tx]) * wgt[ty][tx];
+                float diff = (lk_sample(J, ax[tx], ay[ty]) - Ip[ty][tx]) * wgt[ty][tx];
                 b1 = fmaf(diff, Dx[ty][tx], b1);
                 b2 = fmaf(diff, Dy[ty][tx], b2);
             }
@@ -157,7 +162,7 @@ extern "C" int ofri_lk_compute(ofri_ctx *ctx, const float *im1, const float *im2
     OFRI_REQUIRE(im1 && im2 && U_in && V_in && U_out && V_out, "null pointer");
     OFRI_REQUIRE(rows > 0 && cols > 0 && niter >= 0, "bad shape or niter");
     OFRI_REQUIRE(half_window >= 0 && 2 * half_window + 1 <= 32, "window %d exceeds the 32-sample grid of the kernel", 2 * half_window + 1);
-    OFRI_REQUIRE(rows <= 65535 && (long long)rows * cols < (1LL << 31), "field too large for one launch");
+    OFRI_REQUIRE(rows <= 65535 && (long long)rows * cols < (1LL << 30), "field too large for one launch (32-bit byte offsets)");
     LkParams p;
     p.win_x = p.win_y = 2 * half_window + 1;
     p.half_x = p.half_y = (p.win_x - 1) >> 1;
