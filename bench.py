@@ -240,6 +240,28 @@ def main():
             Ua, Va = step(i)
             Ua.numpy(); Va.numpy()
         result["with_transfer_mpix_s"] = H * W * 3 / (time.perf_counter() - t) / 1e6
+        # the same with the three legs overlapped (piv_ingest.stream_flows): upload of the next pair and download of
+        # the last result on copy streams of their own
+        from piv_ingest import stream_flows
+        n_str = 16
+        g0, g1 = np.ascontiguousarray(f0, dtype=np.uint8), np.ascontiguousarray(f1, dtype=np.uint8)
+        flow = lambda a, b: pyramidal_flow_device(a, b, 3.4, HSOpticalFlowAlgoAdapter([21, 45], args.niter), 2, 1, None)
+        for _ in stream_flows(ctx, ((g0, g1) for _ in range(2)), flow):
+            pass
+        t = time.perf_counter()
+        for _ in stream_flows(ctx, ((g0, g1) for _ in range(n_str)), flow):
+            pass
+        result["with_transfer_streamed_mpix_s"] = H * W * n_str / (time.perf_counter() - t) / 1e6
+        # and with the pair's launches replayed from captured graphs (piv_plan.StreamedPlan)
+        from piv_plan import StreamedPlan
+        sp = StreamedPlan((H, W), 3.4, lambda: HSOpticalFlowAlgoAdapter([21, 45], args.niter), ctx=ctx, pyramidalLevels=2)
+        for _ in sp.flows((g0, g1) for _ in range(3)):
+            pass
+        t = time.perf_counter()
+        for _ in sp.flows((g0, g1) for _ in range(n_str)):
+            pass
+        result["with_transfer_streamed_graph_mpix_s"] = H * W * n_str / (time.perf_counter() - t) / 1e6
+        sp.close()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args.niter)
     elif rank == 0:

@@ -97,3 +97,30 @@ class PlanPool(object):
         for p in self.plans:
             p.close()
             p.ctx.close()
+
+
+class StreamedPlan(object):
+    """Host frame pairs in, host flow fields out, with upload, compute and download overlapped
+    (piv_ingest.stream_flows) and the compute replayed from captured graphs.  Two plans alternate, so that the
+    result of pair i can still be on its way to the host while pair i+1 is computed into the other plan's arrays;
+    a plan is reused only after its last result has been fetched."""
+
+    def __init__(self, shape, FILTER, make_adapter, ctx=None, **plan_args):
+        self.ctx = ctx if ctx is not None else _ofri.context()
+        self.plans = [FlowPlan(shape, FILTER, make_adapter, ctx=self.ctx, **plan_args) for _ in range(2)]
+
+    def flows(self, pairs, range_rule=False):
+        from piv_ingest import stream_flows
+        turn = [0]
+
+        def flow(im0, im1):
+            p = self.plans[turn[0] & 1]
+            turn[0] += 1
+            p.load(im0, im1)
+            return p.run()
+
+        return stream_flows(self.ctx, pairs, flow, range_rule)
+
+    def close(self):
+        for p in self.plans:
+            p.close()

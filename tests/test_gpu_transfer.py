@@ -165,3 +165,36 @@ def test_plan_pool_keeps_pair_order_and_bits():
         Ur, Vr = genericPyramidalOpticalFlow(a.astype(np.float32), b.astype(np.float32), 3.4,
                                              HSOpticalFlowAlgoAdapter([21, 45], 20), 2, 1, None)
         assert U.tobytes() == Ur.tobytes() and V.tobytes() == Vr.tobytes()
+
+
+def test_stream_flows_overlaps_copies_and_keeps_bits(pair):
+    """Upload of the next pair, compute and download of the last result on three streams: same bits, same order
+    as one pair at a time."""
+    import _ofri
+    from piv_ingest import stream_flows
+    from HornSchunck import HSOpticalFlowAlgoAdapter
+    from GenericPyramidalOpticalFlow import pyramidal_flow_device
+    ctx = _ofri.context(0)
+    I0, I1 = (np.clip(x, 0, 255).astype(np.uint8) for x in pair)
+    pairs = [(np.roll(I0, k, axis=1), np.roll(I1, k, axis=1)) for k in range(5)]
+
+    def flow(a, b):
+        return pyramidal_flow_device(a, b, 3.4, HSOpticalFlowAlgoAdapter([21, 45], 20), 2, 1, None)
+
+    want = []
+    for f0, f1 in pairs:
+        U, V = flow(ctx.upload(f0), ctx.upload(f1))
+        want.append((pageable_download(ctx, U), pageable_download(ctx, V)))
+    got = list(stream_flows(ctx, iter(pairs), flow))
+    assert len(got) == len(want)
+    for (U, V), (Ur, Vr) in zip(got, want):
+        assert U.tobytes() == Ur.tobytes() and V.tobytes() == Vr.tobytes()
+    assert list(stream_flows(ctx, iter([]), flow)) == []
+    # the same from two alternating captured plans
+    from piv_plan import StreamedPlan
+    sp = StreamedPlan(I0.shape, 3.4, lambda: HSOpticalFlowAlgoAdapter([21, 45], 20), ctx=ctx, pyramidalLevels=2)
+    got = [(U.copy(), V.copy()) for U, V in sp.flows(iter(pairs))]
+    sp.close()
+    assert len(got) == len(want)
+    for (U, V), (Ur, Vr) in zip(got, want):
+        assert U.tobytes() == Ur.tobytes() and V.tobytes() == Vr.tobytes()
