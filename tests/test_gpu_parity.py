@@ -448,6 +448,39 @@ def test_liushen_stopping_rule_and_tiny_shapes(ctx):
     np.testing.assert_array_equal(ud.numpy(), ur)
 
 
+def test_liushen_stops_at_every_iteration_count(ctx, pair):
+    """The stopping check of a sweep runs inside the next sweep's launch, which has then already started: whatever the
+    count at which the rule is met (odd, even, the last allowed one), the result must be that sweep's, bit for bit,
+    and the count the reference's loop would report."""
+    import ctypes as C
+    import _ofri
+    lib = _ofri.lib()
+    I0, I1 = pair[0][100:230, 60:260].copy(), pair[1][100:230, 60:260].copy()
+    rows, cols = I0.shape
+    a, b, z = ctx.upload(I0), ctx.upload(I1), ctx.zeros(I0.shape)
+
+    def run(maxit, tol):
+        u, v = ctx.empty(I0.shape), ctx.empty(I0.shape)
+        err, it = C.c_double(0.0), C.c_int(0)
+        _ofri.check(lib.ofri_ls_compute(ctx.handle, a.ptr, b.ptr, z.ptr, z.ptr, u.ptr, v.ptr, 5.0, maxit, tol, rows, cols,
+                                        C.byref(err), C.byref(it)))
+        return u.numpy(), v.numpy(), err.value, it.value
+
+    fixed = {k: run(k, 0.0) for k in range(0, 10)}            # tol = 0: exactly k sweeps
+    assert [fixed[k][3] for k in range(10)] == list(range(10))
+    np.testing.assert_array_equal(fixed[0][0], 0.0)
+    errs = [fixed[k][2] for k in range(1, 10)]
+    assert all(e1 > e2 > 0 for e1, e2 in zip(errs, errs[1:])), errs    # the change per sweep shrinks on this pair
+    for k in range(1, 9):
+        tol = 0.5 * (fixed[k][2] + fixed[k + 1][2])           # err_k > tol > err_(k+1): first met by sweep k+1
+        u, v, e, it = run(60, tol)
+        assert it == k + 1 and e == fixed[k + 1][2]
+        np.testing.assert_array_equal(u, fixed[k + 1][0]); np.testing.assert_array_equal(v, fixed[k + 1][1])
+        u, v, e, it = run(k, tol)                             # the cap comes first
+        assert it == k
+        np.testing.assert_array_equal(u, fixed[k][0])
+
+
 def test_driver_hs_plus_liushen_and_ls_main(ctx, pair):
     from HornSchunck import HSOpticalFlowAlgoAdapter as A
     from PhysicsBasedOpticalFlowLiuShen import LiuShenOpticalFlowAlgoAdapter as LS
