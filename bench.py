@@ -36,6 +36,8 @@ def parse():
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--same-device", action="store_true", help="all ranks compute on GPU 0 (rehearsal on a one-GPU box)")
+    ap.add_argument("--liushen", action="store_true", help="add the Liu-Shen refinement (h = 5, Fs_opt 0.48) after Horn-Schunck on "
+                    "every level: with --size 2048 the per-pair work of the 512-pair batch configuration (not the headline metric)")
     ap.add_argument("--force-dist", action="store_true", help="take the multi-rank code path (process group, gather stream, "
                     "barriers) even with one rank: rehearsal of the N > 1 path on a one-GPU box")
     ap.add_argument("--with-transfer", action="store_true", help="also report the rate including H2D/D2H copies")
@@ -117,15 +119,19 @@ def main():
         except Exception as e:                       # keep the compute measurement alive
             gather, gather_note = False, "disabled: %r" % (e,)
 
+    opt_args = {}
+    if args.liushen:
+        from PhysicsBasedOpticalFlowLiuShen import LiuShenOpticalFlowAlgoAdapter
+        opt_args = {"FILTER_OPT": 0.48, "optionalOFlowAlgoAdapter": LiuShenOpticalFlowAlgoAdapter(5)}
     plan = None
     extra = []                      # further (context, plan) pairs when several frame pairs are in flight
     if args.graph:
         from piv_plan import FlowPlan
-        plan = FlowPlan((H, W), 3.4, lambda: HSOpticalFlowAlgoAdapter([21, 45], args.niter), pyramidalLevels=2, ctx=ctx)
+        plan = FlowPlan((H, W), 3.4, lambda: HSOpticalFlowAlgoAdapter([21, 45], args.niter), pyramidalLevels=2, ctx=ctx, **opt_args)
         plan.load(im0, im1)
         for k in range(1, max(1, args.in_flight)):
             c = _ofri.Context(dev)
-            pk = FlowPlan((H, W), 3.4, lambda: HSOpticalFlowAlgoAdapter([21, 45], args.niter), pyramidalLevels=2, ctx=c)
+            pk = FlowPlan((H, W), 3.4, lambda: HSOpticalFlowAlgoAdapter([21, 45], args.niter), pyramidalLevels=2, ctx=c, **opt_args)
             pk.load(*synth_piv(H, W, seed=100 * rank + k))
             c.sync()
             extra.append((c, pk))
@@ -137,7 +143,8 @@ def main():
                 pk.run()
             Ua, Va = plan.run()
         else:
-            Ua, Va = pyramidal_flow_device(im0, im1, 3.4, HSOpticalFlowAlgoAdapter([21, 45], args.niter), 2, 1, None)
+            Ua, Va = pyramidal_flow_device(im0, im1, 3.4, HSOpticalFlowAlgoAdapter([21, 45], args.niter), 2, 1,
+                                           opt_args.get("FILTER_OPT"), opt_args.get("optionalOFlowAlgoAdapter"))
         if gather:
             buf = out_t[i & 1]
             if len(pending) >= 2:
@@ -220,7 +227,7 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "HS Fs3.4, 2-level pyramid, %dx%d synthetic Poiseuille pair, alphas [21,45], "
-                                   "%d sweeps/level" % (H, W, args.niter),
+                                   "%d sweeps/level%s" % (H, W, args.niter, " + Liu-Shen h=5 Fs_opt 0.48 on every level" if args.liushen else ""),
                        "pairs_per_step_per_gpu": pairs_per_step, "flow_gather": gather_note, "captured_graph": bool(args.graph),
                        "hs_sweeps_per_launch": sweeps_per_launch},
             "roofline": {"bound": "hbm", "kernel": "%s@%dx%d" % (kname, H, W), "achieved": achieved,
