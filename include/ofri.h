@@ -195,6 +195,13 @@ int ofri_fb_update_flow(ofri_ctx *ctx, const float *M, float *flowx, float *flow
  * matrices are consumed in registers and never written. */
 int ofri_fb_window5_update_flow(ofri_ctx *ctx, const float *M5, float *flowx, float *flowy, int rows,
                                 int cols, const float *half_taps_host, int ksize_half, int box);
+/* The same followed by updateMatrices for the next iteration, the body of the reference's flow loop when it is
+ * not the last iteration (src/Farneback_PyCL.py:442-457: gaussianBlur5 / boxFilter5, updateFlow, updateMatrices):
+ * one launch for ksize_half 16, the separate steps otherwise.  The new matrices go to M5_next (not M5); flowx and
+ * flowy may both be NULL when the displacement of this iteration is not wanted. */
+int ofri_fb_window5_flow_matrices(ofri_ctx *ctx, const float *M5, float *flowx, float *flowy, const float *R0,
+                                  const float *R1, float *M5_next, int rows, int cols,
+                                  const float *half_taps_host, int ksize_half, int box);
 
 /* ---- dense Lucas-Kanade ----------------------------------------------------------------------------- */
 /* lkDense (src/pyrlkDenseLargeW.cl:304-669) as launched by denseLucasKanade_PyCl.compute

@@ -207,15 +207,21 @@ class Farneback_PyCL(object):
             ksh = int(smoothSize / 2)                        # the reference passes smoothSize/2 through cl.cltypes.int
             RA = self._polyexp(resize_bilinear_device(self._blur(im1, ksh), (width, height)))
             RB = self._polyexp(resize_bilinear_device(self._blur(im2, ksh), (width, height)))
-            M = ctx.empty((5 * height, width))
+            M, Mnext = ctx.empty((5 * height, width)), ctx.empty((5 * height, width))
             self._update_matrices(curX, curY, RA, RB, M)
             if self.useGaussianFilter:
                 self.setGaussianBlurKernel(self.windowSize, self.windowSize / 2 * 0.3)
             wksh = int(self.windowSize / 2)
             for i in range(self.numIters):
-                self._window_flow(M, curX, curY, wksh)
                 if i < self.numIters - 1:
-                    self._update_matrices(curX, curY, RA, RB, M)
+                    # window filter + updateFlow + updateMatrices (:447-457) in one call; the displacement of an
+                    # iteration that is not the last only feeds the matrices of the next
+                    _ofri.check(lib.ofri_fb_window5_flow_matrices(ctx.handle, M.ptr, None, None, RA.ptr, RB.ptr, Mnext.ptr, height, width,
+                                                                  self.matrixGKernel.ctypes.data, wksh,
+                                                                  0 if self.useGaussianFilter else 1))
+                    M, Mnext = Mnext, M
+                else:
+                    self._window_flow(M, curX, curY, wksh)
             prevX, prevY = curX, curY
         return curX, curY, 'Unknown'
 

@@ -73,6 +73,7 @@ _PROTOS = {
     "ofri_fb_update_matrices": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i], _i),
     "ofri_fb_update_flow": ([_vp, _vp, _vp, _vp, _i, _i], _i),
     "ofri_fb_window5_update_flow": ([_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i], _i),
+    "ofri_fb_window5_flow_matrices": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i], _i),
     "ofri_lk_compute": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i], _i),
     "ofri_resize_bicubic": ([_vp, _vp, _i, _i, _vp, _i, _i], _i),
     "ofri_resize_bilinear": ([_vp, _vp, _i, _i, _vp, _i, _i], _i),

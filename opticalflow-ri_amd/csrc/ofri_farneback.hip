@@ -85,6 +85,51 @@ extern "C" int ofri_fb_polyexp(ofri_ctx *ctx, const float *src, float *dst5, int
     return OFRI_OK;
 }
 
+// ---- updateMatrices (.cl:256-348) -------------------------------------------------------------------
+__constant__ float c_fb_border[6] = {0.14f, 0.14f, 0.4472f, 0.4472f, 0.4472f, 1.f};
+
+// the five matrix entries of pixel (y, x) from its displacement (dx, dy) and the two expansions
+__device__ __forceinline__ void fb_matrices_at(int x, int y, float dx, float dy, const float *__restrict__ R0,
+                                               const float *__restrict__ R1, float *__restrict__ M, int H, int W) {
+    const size_t P = (size_t)H * W, o = (size_t)y * W + x;
+    float fx = x + dx, fy = y + dy;
+    // convert_int(floor(.)): saturate so that absurd displacements stay "outside" instead of wrapping
+    float flx = floorf(fx), fly = floorf(fy);
+    int x1 = (int)fminf(fmaxf(flx, -1e9f), 1e9f), y1 = (int)fminf(fmaxf(fly, -1e9f), 1e9f);
+    fx -= x1;
+    fy -= y1;
+    float r2, r3, r4, r5, r6;
+    if (x1 >= 0 && y1 >= 0 && x1 < W - 1 && y1 < H - 1) {
+        float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
+        size_t q = (size_t)y1 * W + x1;
+        const float *p = R1;
+        r2 = a00 * p[q] + a01 * p[q + 1] + a10 * p[q + W] + a11 * p[q + W + 1]; p += P;
+        r3 = a00 * p[q] + a01 * p[q + 1] + a10 * p[q + W] + a11 * p[q + W + 1]; p += P;
+        r4 = a00 * p[q] + a01 * p[q + 1] + a10 * p[q + W] + a11 * p[q + W + 1]; p += P;
+        r5 = a00 * p[q] + a01 * p[q + 1] + a10 * p[q + W] + a11 * p[q + W + 1]; p += P;
+        r6 = a00 * p[q] + a01 * p[q + 1] + a10 * p[q + W] + a11 * p[q + W + 1];
+        r4 = (R0[2 * P + o] + r4) * 0.5f;
+        r5 = (R0[3 * P + o] + r5) * 0.5f;
+        r6 = (R0[4 * P + o] + r6) * 0.25f;
+    } else {
+        r2 = r3 = 0.f;
+        r4 = R0[2 * P + o];
+        r5 = R0[3 * P + o];
+        r6 = R0[4 * P + o] * 0.5f;
+    }
+    r2 = (R0[o] - r2) * 0.5f;
+    r3 = (R0[P + o] - r3) * 0.5f;
+    r2 += r4 * dy + r6 * dx;
+    r3 += r6 * dy + r5 * dx;
+    float scale = c_fb_border[min(x, 5)] * c_fb_border[min(y, 5)] * c_fb_border[min(W - x - 1, 5)] * c_fb_border[min(H - y - 1, 5)];
+    r2 *= scale; r3 *= scale; r4 *= scale; r5 *= scale; r6 *= scale;
+    M[o] = r4 * r4 + r6 * r6;
+    M[P + o] = (r4 + r5) * r6;
+    M[2 * P + o] = r5 * r5 + r6 * r6;
+    M[3 * P + o] = r4 * r2 + r6 * r3;
+    M[4 * P + o] = r6 * r2 + r5 * r3;
+}
+
 // ---- separable window filter on NP stacked planes (.cl:160-253, 350-406) -------------------------
 // One workgroup: 64 x 16 outputs.  Per plane the (16+2k) x (64+2k) source tile goes to LDS once, the
 // vertical pass writes 16 x (64+2k) partial sums to LDS, the horizontal pass leaves 4 results per
@@ -167,11 +212,14 @@ k_fb_window(const float *__restrict__ src, float *__restrict__ dst, float *__res
 // over 256 threads: every wavefront does the same work), the horizontal pass 4 adjacent outputs of one row
 // fetched as nine 16-byte LDS reads, two rows per thread.  Taps are applied in the reference's order (centre,
 // then pairs outward), so results are identical to k_fb_window.
+// UM (with FLOW): the matrices of the next iteration are made from the new displacement on the spot (updateMatrices,
+// a per-pixel step) and stored to Mnext; the displacement itself is stored only where flowx is given.
 #define BW_TY 32
-template <int NP, int MODE, bool FLOW>
+template <int NP, int MODE, bool FLOW, bool UM = false>
 __global__ void __launch_bounds__(256)
 k_fb_window16(const float *__restrict__ src, float *__restrict__ dst, float *__restrict__ flowx, float *__restrict__ flowy,
-              int H, int W, FbTaps taps) {
+              int H, int W, FbTaps taps, const float *__restrict__ R0 = nullptr, const float *__restrict__ R1 = nullptr,
+              float *__restrict__ Mnext = nullptr) {
     constexpr int KSH = 16, TW = BL_TX + 2 * KSH, TH = BW_TY + 2 * KSH;      // 96 x 64
     constexpr int NLD = TH / 8 * 3;                                          // loads per thread and plane
     constexpr int NR = BW_TY / 16;                                           // output rows per thread
@@ -252,6 +300,10 @@ k_fb_window16(const float *__restrict__ src, float *__restrict__ dst, float *__r
     }
     const float box_inv = 1.f / ((1 + 2 * KSH) * (1 + 2 * KSH));
     const int x0 = bx + 4 * xg;
+    // UM: the displacements of the tile go through LDS (the source tile's space: every thread is past its last read of
+    // it), so that the per-pixel step after them runs with one pixel per lane along rows (coalesced gathers and stores)
+    float (*tf)[BW_TY][BL_TX] = reinterpret_cast<float (*)[BW_TY][BL_TX]>(&tin[0][0]);
+    static_assert(sizeof(float) * 2 * BW_TY * BL_TX <= sizeof(float) * TH * TW, "the displacement tile fits in the source tile");
 #pragma unroll
     for (int h = 0; h < NR; ++h) {
         const int y = by + ly + 16 * h;
@@ -267,12 +319,24 @@ k_fb_window16(const float *__restrict__ src, float *__restrict__ dst, float *__r
             if (FLOW) {
                 float g11 = v[0], g12 = v[NP > 1 ? 1 : 0], g22 = v[NP > 2 ? 2 : 0], h1 = v[NP > 3 ? 3 : 0], h2 = v[NP > 4 ? 4 : 0];
                 float detInv = 1.f / (g11 * g22 - g12 * g12 + 1e-3f);
-                flowx[o] = (g11 * h2 - g12 * h1) * detInv;
-                flowy[o] = (g22 * h1 - g12 * h2) * detInv;
+                const float ux = (g11 * h2 - g12 * h1) * detInv, uy = (g22 * h1 - g12 * h2) * detInv;
+                if (UM) { tf[0][ly + 16 * h][4 * xg + k] = ux; tf[1][ly + 16 * h][4 * xg + k] = uy; }
+                else { flowx[o] = ux; flowy[o] = uy; }
             } else {
 #pragma unroll
                 for (int p = 0; p < NP; ++p) dst[p * P + o] = v[p];
             }
+        }
+    }
+    if (FLOW && UM) {
+        __syncthreads();
+#pragma unroll 2
+        for (int j = 0; j < BW_TY / 4; ++j) {
+            const int ry = (tid >> 6) + 4 * j, rx = tid & 63, y = by + ry, x = bx + rx;
+            if (y >= H || x >= W) continue;
+            const float ux = tf[0][ry][rx], uy = tf[1][ry][rx];
+            if (flowx) { flowx[(size_t)y * W + x] = ux; flowy[(size_t)y * W + x] = uy; }
+            fb_matrices_at(x, y, ux, uy, R0, R1, Mnext, H, W);
         }
     }
 }
@@ -322,53 +386,14 @@ extern "C" int ofri_fb_window5_update_flow(ofri_ctx *ctx, const float *M5, float
     return fb_window_launch<5, 0, true>(ctx, M5, nullptr, flowx, flowy, rows, cols, half_taps_host, ksize_half);
 }
 
-// ---- updateMatrices (.cl:256-348) -------------------------------------------------------------------
-__constant__ float c_fb_border[6] = {0.14f, 0.14f, 0.4472f, 0.4472f, 0.4472f, 1.f};
-
 __global__ void k_fb_update_matrices(const float *__restrict__ flowx, const float *__restrict__ flowy,
                                      const float *__restrict__ R0, const float *__restrict__ R1, float *__restrict__ M,
                                      int H, int W) {
     int x = blockIdx.x * blockDim.x + threadIdx.x;
     int y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= W || y >= H) return;
-    const size_t P = (size_t)H * W, o = (size_t)y * W + x;
-    float dx = flowx[o], dy = flowy[o];
-    float fx = x + dx, fy = y + dy;
-    // convert_int(floor(.)): saturate so that absurd displacements stay "outside" instead of wrapping
-    float flx = floorf(fx), fly = floorf(fy);
-    int x1 = (int)fminf(fmaxf(flx, -1e9f), 1e9f), y1 = (int)fminf(fmaxf(fly, -1e9f), 1e9f);
-    fx -= x1;
-    fy -= y1;
-    float r2, r3, r4, r5, r6;
-    if (x1 >= 0 && y1 >= 0 && x1 < W - 1 && y1 < H - 1) {
-        float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
-        size_t q = (size_t)y1 * W + x1;
-        const float *p = R1;
-        r2 = a00 * p[q] + a01 * p[q + 1] + a10 * p[q + W] + a11 * p[q + W + 1]; p += P;
-        r3 = a00 * p[q] + a01 * p[q + 1] + a10 * p[q + W] + a11 * p[q + W + 1]; p += P;
-        r4 = a00 * p[q] + a01 * p[q + 1] + a10 * p[q + W] + a11 * p[q + W + 1]; p += P;
-        r5 = a00 * p[q] + a01 * p[q + 1] + a10 * p[q + W] + a11 * p[q + W + 1]; p += P;
-        r6 = a00 * p[q] + a01 * p[q + 1] + a10 * p[q + W] + a11 * p[q + W + 1];
-        r4 = (R0[2 * P + o] + r4) * 0.5f;
-        r5 = (R0[3 * P + o] + r5) * 0.5f;
-        r6 = (R0[4 * P + o] + r6) * 0.25f;
-    } else {
-        r2 = r3 = 0.f;
-        r4 = R0[2 * P + o];
-        r5 = R0[3 * P + o];
-        r6 = R0[4 * P + o] * 0.5f;
-    }
-    r2 = (R0[o] - r2) * 0.5f;
-    r3 = (R0[P + o] - r3) * 0.5f;
-    r2 += r4 * dy + r6 * dx;
-    r3 += r6 * dy + r5 * dx;
-    float scale = c_fb_border[min(x, 5)] * c_fb_border[min(y, 5)] * c_fb_border[min(W - x - 1, 5)] * c_fb_border[min(H - y - 1, 5)];
-    r2 *= scale; r3 *= scale; r4 *= scale; r5 *= scale; r6 *= scale;
-    M[o] = r4 * r4 + r6 * r6;
-    M[P + o] = (r4 + r5) * r6;
-    M[2 * P + o] = r5 * r5 + r6 * r6;
-    M[3 * P + o] = r4 * r2 + r6 * r3;
-    M[4 * P + o] = r6 * r2 + r5 * r3;
+    const size_t o = (size_t)y * W + x;
+    fb_matrices_at(x, y, flowx[o], flowy[o], R0, R1, M, H, W);
 }
 
 extern "C" int ofri_fb_update_matrices(ofri_ctx *ctx, const float *flowx, const float *flowy, const float *R0,
@@ -380,6 +405,37 @@ extern "C" int ofri_fb_update_matrices(ofri_ctx *ctx, const float *flowx, const 
     k_fb_update_matrices<<<g, b, 0, ctx->stream>>>(flowx, flowy, R0, R1, M, rows, cols);
     OFRI_LAUNCH_CHECK();
     return OFRI_OK;
+}
+
+// One iteration of the reference's flow loop from the second on (Farneback_PyCL.py:442-457): window filter of the matrices
+// + 2x2 solve + the next matrices in one launch for the default window (ksize_half 16, Gaussian or box); otherwise the
+// separate steps.  flowx, flowy may be null when the displacement of this iteration is not wanted (the fused launch then
+// does not store it); M5_next must not be M5.
+extern "C" int ofri_fb_window5_flow_matrices(ofri_ctx *ctx, const float *M5, float *flowx, float *flowy, const float *R0,
+                                             const float *R1, float *M5_next, int rows, int cols,
+                                             const float *half_taps_host, int ksize_half, int box) {
+    OFRI_TRY(ofri_check_ctx(ctx));
+    OFRI_REQUIRE(M5 && R0 && R1 && M5_next && M5_next != M5, "null or aliased pointer");
+    OFRI_REQUIRE((flowx == nullptr) == (flowy == nullptr), "flowx and flowy must both be given or both be null");
+    OFRI_REQUIRE(rows > 0 && cols > 0, "bad shape");
+    OFRI_REQUIRE(box || half_taps_host, "null taps");
+    if (ksize_half == 16 && (size_t)rows * cols < 0xffffffffull) {
+        FbTaps t;
+        memset(&t, 0, sizeof(t));
+        if (!box) memcpy(t.k, half_taps_host, 17 * sizeof(float));
+        dim3 g16(ceil_div(cols, BL_TX), ceil_div(rows, BW_TY));
+        if (box) k_fb_window16<5, 1, true, true><<<g16, 256, 0, ctx->stream>>>(M5, nullptr, flowx, flowy, rows, cols, t, R0, R1, M5_next);
+        else k_fb_window16<5, 0, true, true><<<g16, 256, 0, ctx->stream>>>(M5, nullptr, flowx, flowy, rows, cols, t, R0, R1, M5_next);
+        OFRI_LAUNCH_CHECK();
+        return OFRI_OK;
+    }
+    PoolBuf tx(ctx), ty(ctx);
+    if (!flowx) {
+        OFRI_TRY(tx.get((size_t)rows * cols * sizeof(float))); OFRI_TRY(ty.get((size_t)rows * cols * sizeof(float)));
+        flowx = tx.as<float>(); flowy = ty.as<float>();
+    }
+    OFRI_TRY(ofri_fb_window5_update_flow(ctx, M5, flowx, flowy, rows, cols, half_taps_host, ksize_half, box));
+    return ofri_fb_update_matrices(ctx, flowx, flowy, R0, R1, M5_next, rows, cols);
 }
 
 // ---- updateFlow (.cl:408-429) -----------------------------------------------------------------------

@@ -535,6 +535,31 @@ def test_farneback_kernels_bit_exact_vs_oracle(ctx, shape):
     np.testing.assert_array_equal(ux, uxo); np.testing.assert_array_equal(uy, uyo)
 
 
+
+@pytest.mark.parametrize("shape,ksh,box", [((70, 130), 16, 0), ((33, 64), 16, 1), ((40, 100), 7, 0), ((128, 256), 16, 0)])
+def test_farneback_fused_iteration_equals_its_steps(ctx, shape, ksh, box):
+    """Window filter + updateFlow + updateMatrices in one call: the same bits as the three steps, with and without
+    the displacement stored."""
+    import _ofri
+    from GaussianKernelBitExact import getGaussianKernelBitExact
+    lib = _ofri.lib()
+    H, W = shape
+    rng = np.random.default_rng(H * 31 + W + ksh)
+    M = ctx.upload((rng.standard_normal((5 * H, W)) * 3).astype(np.float32))
+    R0 = ctx.upload(rng.standard_normal((5 * H, W)).astype(np.float32)); R1 = ctx.upload(rng.standard_normal((5 * H, W)).astype(np.float32))
+    taps = np.ascontiguousarray(getGaussianKernelBitExact(2 * ksh + 1, 0.3 * ksh)[ksh:], dtype=np.float32)
+    fx, fy, Mref = ctx.empty(shape), ctx.empty(shape), ctx.empty((5 * H, W))
+    _ofri.check(lib.ofri_fb_window5_update_flow(ctx.handle, M.ptr, fx.ptr, fy.ptr, H, W, taps.ctypes.data, ksh, box))
+    _ofri.check(lib.ofri_fb_update_matrices(ctx.handle, fx.ptr, fy.ptr, R0.ptr, R1.ptr, Mref.ptr, H, W))
+    gx, gy, Mn = ctx.zeros(shape), ctx.zeros(shape), ctx.zeros((5 * H, W))
+    _ofri.check(lib.ofri_fb_window5_flow_matrices(ctx.handle, M.ptr, gx.ptr, gy.ptr, R0.ptr, R1.ptr, Mn.ptr, H, W, taps.ctypes.data, ksh, box))
+    assert gx.numpy().tobytes() == fx.numpy().tobytes() and gy.numpy().tobytes() == fy.numpy().tobytes()
+    assert Mn.numpy().tobytes() == Mref.numpy().tobytes()
+    Mn2 = ctx.zeros((5 * H, W))
+    _ofri.check(lib.ofri_fb_window5_flow_matrices(ctx.handle, M.ptr, None, None, R0.ptr, R1.ptr, Mn2.ptr, H, W, taps.ctypes.data, ksh, box))
+    assert Mn2.numpy().tobytes() == Mref.numpy().tobytes()
+    assert lib.ofri_fb_window5_flow_matrices(ctx.handle, M.ptr, None, None, R0.ptr, R1.ptr, M.ptr, H, W, taps.ctypes.data, ksh, box) != 0
+
 @pytest.mark.parametrize("kw", [dict(), dict(useGaussian=False, windowSize=15, Niters=3, polyN=5, polySigma=1.1),
                                 dict(pyramidalLevels=3)])
 def test_farneback_compute_vs_oracle(ctx, kw):
