@@ -18,10 +18,10 @@ from GenericPyramidalOpticalFlow import pyramidal_flow_device
 
 class FlowPlan(object):
     """``make_adapter``: a callable that returns a fresh main adapter (adapters consume their parameter lists, so
-    every run of the driver needs a new one).  Works for sequences that never wait for the GPU: Horn-Schunck and
-    Liu-Shen (whose stopping rule stays on the GPU) with the bilinear warp.  Sequences that read something back
-    (the biLinear=False warp's range check) or upload per-call host tables (Farneback, dense LK) raise OfriError
-    at construction."""
+    every run of the driver needs a new one).  Works for sequences that never wait for the GPU: all four adapters
+    (Liu-Shen's stopping rule stays on the GPU; filter taps and window parameters are kernel arguments) with the
+    bilinear warp or none.  Sequences that read something back (the biLinear=False warp's range check) raise
+    OfriError at construction."""
 
     def __init__(self, shape, FILTER, make_adapter, pyramidalLevels=1, kLevels=1, FILTER_OPT=None, ctx=None, **driver_args):
         self.ctx = ctx if ctx is not None else _ofri.context()

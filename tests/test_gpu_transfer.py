@@ -118,6 +118,24 @@ def test_flow_plan_replays_the_driver_bit_for_bit(shape, levels):
     plan.close()
 
 
+def test_flow_plan_with_farneback_and_dense_lk(pair):
+    """Their per-call constants (filter taps, expansion tables, window parameters) travel as kernel arguments, so
+    the other two main adapters replay from a captured graph too."""
+    from GenericPyramidalOpticalFlow import genericPyramidalOpticalFlow
+    from Farneback_PyCL import Farneback_PyCL
+    from denseLucasKanade_PyCL import denseLucasKanade_PyCl
+    from piv_plan import FlowPlan
+    for make, crop in ((lambda: Farneback_PyCL(), 256), (lambda: denseLucasKanade_PyCl(Niter=3, halfWindow=6), 96)):
+        I0, I1 = pair[0][:crop, :crop].copy(), pair[1][:crop, :crop].copy()
+        plan = FlowPlan(I0.shape, 2.0, make, pyramidalLevels=2)
+        for k in range(2):
+            a, b = np.roll(I0, 3 * k, axis=0), np.roll(I1, 3 * k, axis=0)
+            U, V = plan(a, b)
+            Ur, Vr = genericPyramidalOpticalFlow(a.copy(), b.copy(), 2.0, make(), 2, 1, None)
+            assert U.tobytes() == Ur.tobytes() and V.tobytes() == Vr.tobytes()
+        plan.close()
+
+
 def test_flow_plan_with_liushen_refinement(pair):
     """Liu-Shen keeps its stopping rule on the GPU, so Horn-Schunck + Liu-Shen (the reference's LiuSE examples) is
     capturable too."""
