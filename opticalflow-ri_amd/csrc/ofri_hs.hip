@@ -238,6 +238,40 @@ static int hs_stream_path(ofri_ctx *ctx, const float *Uin, const float *Vin, flo
     return OFRI_OK;
 }
 
+// Widths that are not a multiple of 4: the tile kernel on padded copies (row pitch rounded up to 4 floats, so every row
+// is 16-byte aligned and a strip that straddles the right edge has room for its last columns), seven planes in one
+// block: two U/V pairs and the scaled coefficients.  Same arguments as hs_iterate_io; niter > 0.
+static int hs_iterate_padded(ofri_ctx *ctx, const float *Uin, const float *Vin, float *Uout, float *Vout, const float *fx,
+                             const float *fy, const float *ft, float a2, int niter, int rows, int cols, bool frames) {
+    const int P = (cols + 3) & ~3;
+    const size_t plane = (size_t)rows * P, wbytes = (size_t)cols * sizeof(float), pbytes = (size_t)P * sizeof(float);
+    PoolBuf buf(ctx);
+    OFRI_TRY(buf.get(7 * plane * sizeof(float)));
+    float *base = buf.as<float>();
+    float *U[2] = {base, base + 2 * plane}, *V[2] = {base + plane, base + 3 * plane};
+    float *A = base + 4 * plane, *B = base + 5 * plane, *C = base + 6 * plane;
+    OFRI_REQUIRE((((size_t)base) & 15) == 0, "pool block is not 16-byte aligned");
+    OFRI_HIP(hipMemcpy2DAsync(U[0], pbytes, Uin, wbytes, wbytes, rows, hipMemcpyDeviceToDevice, ctx->stream));
+    OFRI_HIP(hipMemcpy2DAsync(V[0], pbytes, Vin, wbytes, wbytes, rows, hipMemcpyDeviceToDevice, ctx->stream));
+    OFRI_TRY(ofri_hs_scaled_coefs(ctx, frames ? nullptr : fx, fy, ft, fx, fy, A, B, C, a2, rows, cols, P));
+    int Tmax = ofri_hs_fused_max_sweeps();
+    if (ctx->hs_fuse > 1 && ctx->hs_fuse < Tmax) Tmax = ctx->hs_fuse;
+    const int L = (niter + Tmax - 1) / Tmax;
+    ofri_ctx::ProfRec rec{};
+    OFRI_TRY(prof_begin(ctx, rec));
+    int remaining = niter, cur = 0;
+    for (int k = 0; k < L; ++k) {
+        const int T = remaining < Tmax ? remaining : Tmax;
+        OFRI_TRY(ofri_hs_fused_launch_pitched(ctx, U[cur], V[cur], U[cur ^ 1], V[cur ^ 1], A, B, C, T, rows, cols, P, P, P, false));
+        cur ^= 1;
+        remaining -= T;
+    }
+    OFRI_TRY(prof_end(ctx, rec, rows, cols, L, niter));
+    OFRI_HIP(hipMemcpy2DAsync(Uout, wbytes, U[cur], pbytes, wbytes, rows, hipMemcpyDeviceToDevice, ctx->stream));
+    OFRI_HIP(hipMemcpy2DAsync(Vout, wbytes, V[cur], pbytes, wbytes, rows, hipMemcpyDeviceToDevice, ctx->stream));
+    return OFRI_OK;
+}
+
 // niter sweeps from (Uin, Vin) into (Uout, Vout); Uin/Vin may alias Uout/Vout.  Launches ping-pong between
 // the output planes and two pooled scratch planes, arranged so that the last launch lands in the output.
 // frames: (fx, fy) are the two images computeDerivatives takes and ft is a spare plane; the coefficients are made here.
@@ -257,6 +291,8 @@ static int hs_iterate_io(ofri_ctx *ctx, const float *Uin, const float *Vin, floa
         if (n_stream > 0)
             return hs_stream_path(ctx, Uin, Vin, Uout, Vout, fx, fy, ft, nullptr, nullptr, a2, niter, n_stream, rows, cols);
     }
+    if (!exact && ctx->hs_fuse != 1 && (cols & 3) != 0 && cols >= 16 && rows >= 16)
+        return hs_iterate_padded(ctx, Uin, Vin, Uout, Vout, fx, fy, ft, a2, niter, rows, cols, frames);
     PoolBuf tu(ctx), tv(ctx), ca(ctx), cb(ctx), cc(ctx);
     OFRI_TRY(tu.get(bytes));
     OFRI_TRY(tv.get(bytes));

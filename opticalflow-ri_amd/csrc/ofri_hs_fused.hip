@@ -156,8 +156,10 @@ k_hs_fused(const float *__restrict__ U, const float *__restrict__ V, const float
     }
     if (s < T) ft_sweep<FT_S>(edge, ftile, 0, band, l32, cu, cv, gx, gy);
 
-    // store the inner tile: bands 1..FT_BANDS-2, strips 2..29, clipped to the image
-    if (band >= FT_HALO / FT_S && band < FT_BANDS - FT_HALO / FT_S && l32 >= FT_HALO / 4 && l32 < 32 - FT_HALO / 4 && xin) {
+    // store the inner tile: bands 1..FT_BANDS-2, strips 2..29, clipped to the image.  A strip that straddles the right
+    // edge (width not a multiple of 4) is stored whole: the destination's pitch is a multiple of 4, so its last
+    // columns land in the row's padding.
+    if (band >= FT_HALO / FT_S && band < FT_BANDS - FT_HALO / FT_S && l32 >= FT_HALO / 4 && l32 < 32 - FT_HALO / 4 && gx0 >= 0 && gx0 < W) {
 #pragma unroll
         for (int r = 0; r < FT_S; ++r) {
             int y = gyb + r;
@@ -176,7 +178,8 @@ k_hs_fused(const float *__restrict__ U, const float *__restrict__ V, const float
     }
 }
 
-// The fused kernel needs 16-byte aligned planes, a width that is a multiple of 4 and at least 16 x 16 pixels.
+// The fused kernel needs 16-byte aligned planes whose pitch is a multiple of 4 and at least 16 x 16 pixels; this is
+// the test for dense planes (pitch = width).  Other widths go through padded copies (ofri_hs.hip).
 bool ofri_hs_fused_ok(const void *const *ptrs, int nptrs, int H, int W) {
     size_t bits = 0;
     for (int i = 0; i < nptrs; ++i) bits |= (size_t)ptrs[i];
@@ -185,7 +188,7 @@ bool ofri_hs_fused_ok(const void *const *ptrs, int nptrs, int H, int W) {
 int ofri_hs_fused_max_sweeps(void) { return FT_HALO; }
 
 // One launch: T <= FT_HALO sweeps from (su, sv) into (du, dv); source and destination must differ.  Every
-// pointer is at pixel (0,0) of its plane; pin, pc, pout are the row pitches (in floats, multiples of 4) of the
+// pointer is at pixel (0,0) of its plane; pin, pc, pout are the row pitches (in floats, multiples of 4, at least W) of the
 // source, coefficient and destination planes; fx, fy, ft hold the scaled coefficients A, B, C.  accumulate: the result is added to what (du, dv) hold.
 int ofri_hs_fused_launch_pitched(ofri_ctx *ctx, const float *su, const float *sv, float *du, float *dv, const float *fx,
                                  const float *fy, const float *ft, int T, int H, int W, int pin, int pc, int pout,

@@ -266,16 +266,17 @@ k_hs_stream(SlPlanes in, float *__restrict__ Uo, float *__restrict__ Vo, int H, 
 // ---- coefficient planes -------------------------------------------------------------------------------
 // Scaled coefficients A, B, C (hs_scaled).  FRAMES: differentiated on the spot from the two frames (ca = first,
 // cb = second image of computeDerivatives); otherwise ca, cb, cc are fx, fy, ft (and may be the output planes).
+// The inputs are dense; po is the row pitch of the output planes.
 template <bool FRAMES>
 __global__ void k_sl_coefs(const float *ca, const float *cb, const float *cc, float *oa, float *ob, float *oc,
-                           int H, int W, float a2) {
+                           int H, int W, int po, float a2) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= W || y >= H) return;
-    const size_t s = (size_t)y * W + x;
+    const size_t s = (size_t)y * W + x, d = (size_t)y * po + x;
     float gx, gy, gt;
     if (FRAMES) hs_derivs_at(ca, cb, y, x, H, W, gx, gy, gt);
     else { gx = ca[s]; gy = cb[s]; gt = cc[s]; }
-    hs_scaled(gx, gy, gt, a2, oa[s], ob[s], oc[s]);
+    hs_scaled(gx, gy, gt, a2, oa[d], ob[d], oc[d]);
 }
 
 int ofri_hs_stream_sweeps(void) { return SL_NL_MAIN; }
@@ -303,10 +304,11 @@ int ofri_sl_fill(ofri_ctx *ctx, OfriSlSet &s, const float *U, const float *V, co
     return ofri_hs_scaled_coefs(ctx, fx, fy, ft, first, second, s.fx, s.fy, s.ft, a2, H, W);
 }
 int ofri_hs_scaled_coefs(ofri_ctx *ctx, const float *fx, const float *fy, const float *ft, const float *first,
-                         const float *second, float *A, float *B, float *C, float a2, int H, int W) {
+                         const float *second, float *A, float *B, float *C, float a2, int H, int W, int pitch_out) {
+    if (pitch_out <= 0) pitch_out = W;
     dim3 b(64, 4), g(ceil_div(W, 64), ceil_div(H, 4));
-    if (fx) k_sl_coefs<false><<<g, b, 0, ctx->stream>>>(fx, fy, ft, A, B, C, H, W, a2);
-    else k_sl_coefs<true><<<g, b, 0, ctx->stream>>>(first, second, nullptr, A, B, C, H, W, a2);
+    if (fx) k_sl_coefs<false><<<g, b, 0, ctx->stream>>>(fx, fy, ft, A, B, C, H, W, pitch_out, a2);
+    else k_sl_coefs<true><<<g, b, 0, ctx->stream>>>(first, second, nullptr, A, B, C, H, W, pitch_out, a2);
     OFRI_LAUNCH_CHECK();
     return OFRI_OK;
 }

@@ -137,7 +137,10 @@ def test_hs_ragged_shapes_vs_oracle(ctx, shape):
 
 
 @pytest.mark.parametrize("shape,nit", [((1, 8), 5), ((5, 12), 16), ((40, 200), 33), ((300, 100), 17), ((257, 1000), 48),
-                                       ((700, 96), 100), ((64, 2052), 20)])
+                                       ((700, 96), 100), ((64, 2052), 20),
+                                       # widths that are not multiples of 4: the tile kernel runs on padded copies
+                                       ((16, 17), 9), ((40, 201), 33), ((300, 99), 17), ((130, 1023), 20), ((64, 2050), 12),
+                                       ((113, 114), 8), ((48, 115), 24)])
 def test_hs_launch_shapes_agree_bitwise(ctx, shape, nit):
     """One sweep per launch, the tile kernel (8 sweeps per launch) and the row-streaming pipeline
     (16 per launch) share one arithmetic sequence: their results are the same bits."""
