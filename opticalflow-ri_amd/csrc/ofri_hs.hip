@@ -195,13 +195,9 @@ static int hs_stream_share(ofri_ctx *ctx, const void *const *ptrs, int nptrs, in
     if ((bits & 15) != 0 || (cols & 3) != 0 || cols < 8 || niter <= 0) return 0;
     if (ctx->hs_fuse == 16) return niter;
     const int per = ofri_hs_stream_sweeps();
-    if (ctx->hs_fuse == 0 && ofri_hs_stream_pays(rows, cols) && niter >= 2 * per) {
-        // A pipeline launch costs the same for 1 to 12 sweeps.  On the largest fields that is less than the tile kernel
-        // needs for the left-over sweeps (4096 x 4096, 4 sweeps added to the flow so far: 165 against 189 us); at
-        // 2048 x 2048 the tile kernel wins (38 against 56 us).
-        if ((long long)rows * cols >= 8000000LL) return niter;
-        return niter / per * per;
-    }
+    // the left-over sweeps stay with the tile kernel: a pipeline launch costs the same for 1 to 12 sweeps (4 sweeps added to
+    // the flow so far at 4096 x 4096: 182 us against 189 us in the tile kernel; at 2048 x 2048: 56 against 38 us)
+    if (ctx->hs_fuse == 0 && ofri_hs_stream_pays(rows, cols) && niter >= 2 * per) return niter / per * per;
     return 0;
 }
 
