@@ -177,6 +177,12 @@ int ofri_ls_compute(ofri_ctx *ctx, const float *im1, const float *im2, const flo
  * g/xg/xxg_host are the non-negative halves (polyN+1 floats), ig_host = {ig11, ig03, ig33, ig55}. */
 int ofri_fb_polyexp(ofri_ctx *ctx, const float *src, float *dst5, int rows, int cols, int polyN,
                     const float *g_host, const float *xg_host, const float *xxg_host, const float *ig_host);
+/* gaussianBlur followed by polynomialExpansion of the blurred frame, the way Farneback_PyCL.compute prepares
+ * each frame of a level (src/Farneback_PyCL.py:563-585) when the level has the frame's own size: one launch for
+ * the 3-tap pre-blur (ksize_half 1), the two steps otherwise; same bits as ofri_fb_blur + ofri_fb_polyexp. */
+int ofri_fb_blur_polyexp(ofri_ctx *ctx, const float *src, float *dst5, int rows, int cols,
+                         const float *blur_half_taps_host, int ksize_half, int polyN, const float *g_host,
+                         const float *xg_host, const float *xxg_host, const float *ig_host);
 /* gaussianBlur / gaussianBlur5 (.cl:160-253; host :211-272): separable, reflect-101 borders,
  * half_taps_host = centre tap first, ksize_half+1 floats (ksize_half <= 100). */
 int ofri_fb_blur(ofri_ctx *ctx, const float *src, float *dst, int rows, int cols,

@@ -106,6 +106,15 @@ class Farneback_PyCL(object):
                                                 self.matrixXXG.ctypes.data, self.matrixIG.ctypes.data))
         return out
 
+    def _blur_polyexp(self, src, ksh):
+        """gaussianBlur with the taps set last, then polynomialExpansion, without the blurred frame in memory."""
+        h, w = src.shape
+        out = src.ctx.empty((5 * h, w))
+        _ofri.check(_ofri.lib().ofri_fb_blur_polyexp(src.ctx.handle, src.ptr, out.ptr, h, w, self.matrixGKernel.ctypes.data,
+                                                     int(ksh), self.polyN, self.matrixG.ctypes.data, self.matrixXG.ctypes.data,
+                                                     self.matrixXXG.ctypes.data, self.matrixIG.ctypes.data))
+        return out
+
     def _update_matrices(self, fx, fy, RA, RB, M):
         h, w = fx.shape
         _ofri.check(_ofri.lib().ofri_fb_update_matrices(fx.ctx.handle, fx.ptr, fy.ptr, RA.ptr, RB.ptr, M.ptr, h, w))
@@ -205,8 +214,11 @@ class Farneback_PyCL(object):
                 _ofri.check(lib.ofri_scale_inplace(ctx.handle, curY.ptr, float(mult), curY.size))
             self.setGaussianBlurKernel(smoothSize, sigma)
             ksh = int(smoothSize / 2)                        # the reference passes smoothSize/2 through cl.cltypes.int
-            RA = self._polyexp(resize_bilinear_device(self._blur(im1, ksh), (width, height)))
-            RB = self._polyexp(resize_bilinear_device(self._blur(im2, ksh), (width, height)))
+            if (height, width) == tuple(size):               # the resize between blur and expansion (:570-585) is an identity
+                RA, RB = self._blur_polyexp(im1, ksh), self._blur_polyexp(im2, ksh)
+            else:
+                RA = self._polyexp(resize_bilinear_device(self._blur(im1, ksh), (width, height)))
+                RB = self._polyexp(resize_bilinear_device(self._blur(im2, ksh), (width, height)))
             M, Mnext = ctx.empty((5 * height, width)), ctx.empty((5 * height, width))
             self._update_matrices(curX, curY, RA, RB, M)
             if self.useGaussianFilter:

@@ -67,6 +67,7 @@ _PROTOS = {
     "ofri_hs_level": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _i, _i], _i),
     "ofri_ls_compute": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _d, _i, _i, C.POINTER(_d), C.POINTER(_i)], _i),
     "ofri_fb_polyexp": ([_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp], _i),
+    "ofri_fb_blur_polyexp": ([_vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp], _i),
     "ofri_fb_blur": ([_vp, _vp, _vp, _i, _i, _vp, _i], _i),
     "ofri_fb_blur5": ([_vp, _vp, _vp, _i, _i, _vp, _i], _i),
     "ofri_fb_box5": ([_vp, _vp, _vp, _i, _i, _i], _i),

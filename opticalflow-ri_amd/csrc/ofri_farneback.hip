@@ -85,6 +85,91 @@ extern "C" int ofri_fb_polyexp(ofri_ctx *ctx, const float *src, float *dst5, int
     return OFRI_OK;
 }
 
+// ---- pre-blur + polynomial expansion in one launch --------------------------------------------------
+// The reference blurs every frame with a 3-tap kernel before expanding it (Farneback_PyCL.py:563-585; with the
+// default single internal level the resize between the two is an identity).  Here a workgroup stages the source
+// tile of its 64 x 16 outputs (polyN + 1 more on every side, reflect-101 like gaussianBlur), blurs it in LDS
+// (vertical pass, then horizontal, the order and arithmetic of k_fb_window) and expands the blurred tile with the
+// arithmetic of k_fb_polyexp, whose rows and columns are clamped to the image: same bits as the two kernels.
+#define BP_TX 64
+#define BP_TY 16
+template <int N>
+__global__ void __launch_bounds__(256)
+k_fb_blur3_polyexp(const float *__restrict__ src, float *__restrict__ dst, int H, int W, float k0, float k1, FbPoly c) {
+    constexpr int SW = BP_TX + 2 * N + 2, SH = BP_TY + 2 * N + 2;     // source tile
+    constexpr int BW = BP_TX + 2 * N, BH = BP_TY + 2 * N;             // blurred tile: image rows by-N .., columns bx-N ..
+    __shared__ float pool[SH * SW + BH * SW];                         // source tile + vertical pass; later r0, r1, r2
+    __shared__ float B[BH][BW];
+    static_assert(3 * BP_TY * BW <= SH * SW + BH * SW, "the three partial-sum planes fit where the blur's tiles were");
+    float (*S)[SW] = reinterpret_cast<float (*)[SW]>(pool);
+    float (*V)[SW] = reinterpret_cast<float (*)[SW]>(pool + SH * SW);
+    float (*r0)[BW] = reinterpret_cast<float (*)[BW]>(pool);
+    float (*r1)[BW] = reinterpret_cast<float (*)[BW]>(pool + BP_TY * BW);
+    float (*r2)[BW] = reinterpret_cast<float (*)[BW]>(pool + 2 * BP_TY * BW);
+    const int bx = blockIdx.x * BP_TX, by = blockIdx.y * BP_TY, tid = threadIdx.x;
+    for (int i = tid; i < SH * SW; i += 256) {
+        const int ly = i / SW, lx = i - ly * SW;
+        const int y = fb_idx(by - N - 1 + ly, H - 1), x = fb_idx(bx - N - 1 + lx, W - 1);
+        S[ly][lx] = src[(size_t)y * W + x];
+    }
+    __syncthreads();
+    for (int i = tid; i < BH * SW; i += 256) {
+        const int ly = i / SW, lx = i - ly * SW;
+        float acc = S[ly + 1][lx] * k0;
+        acc += (S[ly][lx] + S[ly + 2][lx]) * k1;
+        V[ly][lx] = acc;
+    }
+    __syncthreads();
+    for (int i = tid; i < BH * BW; i += 256) {
+        const int ly = i / BW, lx = i - ly * BW;
+        float acc = V[ly][lx + 1] * k0;
+        acc += (V[ly][lx] + V[ly][lx + 2]) * k1;
+        B[ly][lx] = acc;
+    }
+    __syncthreads();
+    // expansion, vertical pass; rows clamped (:98-99), columns clamped (:89).  Entries of B outside the image are never read.
+    for (int i = tid; i < BP_TY * BW; i += 256) {
+        const int ly = i / BW, lx = i - ly * BW;
+        const int y = by + ly, col = clampi(bx + lx - N, 0, W - 1) - (bx - N);
+        float a = 0.f, b = 0.f, d = 0.f;
+        if (y < H) {
+            a = B[ly + N][col] * c.g[0];
+#pragma unroll
+            for (int k = 1; k <= N; ++k) {
+                float t0 = B[max(y - k, 0) - (by - N)][col];
+                float t1 = B[min(y + k, H - 1) - (by - N)][col];
+                a += c.g[k] * (t0 + t1);
+                b += c.xg[k] * (t1 - t0);
+                d += c.xxg[k] * (t0 + t1);
+            }
+        }
+        r0[ly][lx] = a; r1[ly][lx] = b; r2[ly][lx] = d;
+    }
+    __syncthreads();
+    for (int i = tid; i < BP_TY * BP_TX; i += 256) {
+        const int ly = i / BP_TX, lx = i - ly * BP_TX;
+        const int y = by + ly, x = bx + lx;
+        if (y >= H || x >= W) continue;
+        const float *p0 = &r0[ly][lx + N], *p1 = &r1[ly][lx + N], *p2 = &r2[ly][lx + N];
+        float b1 = c.g[0] * p0[0], b3 = c.g[0] * p1[0], b5 = c.g[0] * p2[0], b2 = 0.f, b4 = 0.f, b6 = 0.f;
+#pragma unroll
+        for (int k = 1; k <= N; ++k) {
+            b1 += (p0[k] + p0[-k]) * c.g[k];
+            b4 += (p0[k] + p0[-k]) * c.xxg[k];
+            b2 += (p0[k] - p0[-k]) * c.xg[k];
+            b3 += (p1[k] + p1[-k]) * c.g[k];
+            b6 += (p1[k] - p1[-k]) * c.xg[k];
+            b5 += (p2[k] + p2[-k]) * c.g[k];
+        }
+        size_t o = (size_t)y * W + x, P = (size_t)H * W;
+        dst[o] = b3 * c.ig[0];
+        dst[P + o] = b2 * c.ig[0];
+        dst[2 * P + o] = b1 * c.ig[1] + b5 * c.ig[2];
+        dst[3 * P + o] = b1 * c.ig[1] + b4 * c.ig[2];
+        dst[4 * P + o] = b6 * c.ig[3];
+    }
+}
+
 // ---- updateMatrices (.cl:256-348) -------------------------------------------------------------------
 __constant__ float c_fb_border[6] = {0.14f, 0.14f, 0.4472f, 0.4472f, 0.4472f, 1.f};
 
@@ -436,6 +521,34 @@ extern "C" int ofri_fb_window5_flow_matrices(ofri_ctx *ctx, const float *M5, flo
     }
     OFRI_TRY(ofri_fb_window5_update_flow(ctx, M5, flowx, flowy, rows, cols, half_taps_host, ksize_half, box));
     return ofri_fb_update_matrices(ctx, flowx, flowy, R0, R1, M5_next, rows, cols);
+}
+
+// gaussianBlur followed by polynomialExpansion of the blurred image (same size): one launch for the 3-tap blur
+// (ksize_half 1, the reference's pre-blur with one internal pyramid level), the two steps otherwise.
+extern "C" int ofri_fb_blur_polyexp(ofri_ctx *ctx, const float *src, float *dst5, int rows, int cols,
+                                    const float *blur_half_taps_host, int ksize_half, int polyN, const float *g_host,
+                                    const float *xg_host, const float *xxg_host, const float *ig_host) {
+    OFRI_TRY(ofri_check_ctx(ctx));
+    OFRI_REQUIRE(src && dst5 && blur_half_taps_host && g_host && xg_host && xxg_host && ig_host, "null pointer");
+    OFRI_REQUIRE(rows > 0 && cols > 0, "bad shape");
+    OFRI_REQUIRE(polyN == 5 || polyN == 7, "polyN must be 5 or 7");
+    if (ksize_half != 1) {
+        PoolBuf tmp(ctx);
+        OFRI_TRY(tmp.get((size_t)rows * cols * sizeof(float)));
+        OFRI_TRY(ofri_fb_blur(ctx, src, tmp.as<float>(), rows, cols, blur_half_taps_host, ksize_half));
+        return ofri_fb_polyexp(ctx, tmp.as<float>(), dst5, rows, cols, polyN, g_host, xg_host, xxg_host, ig_host);
+    }
+    FbPoly c;
+    memset(&c, 0, sizeof(c));
+    memcpy(c.g, g_host, (polyN + 1) * sizeof(float));
+    memcpy(c.xg, xg_host, (polyN + 1) * sizeof(float));
+    memcpy(c.xxg, xxg_host, (polyN + 1) * sizeof(float));
+    memcpy(c.ig, ig_host, 4 * sizeof(float));
+    dim3 g(ceil_div(cols, BP_TX), ceil_div(rows, BP_TY));
+    if (polyN == 5) k_fb_blur3_polyexp<5><<<g, 256, 0, ctx->stream>>>(src, dst5, rows, cols, blur_half_taps_host[0], blur_half_taps_host[1], c);
+    else k_fb_blur3_polyexp<7><<<g, 256, 0, ctx->stream>>>(src, dst5, rows, cols, blur_half_taps_host[0], blur_half_taps_host[1], c);
+    OFRI_LAUNCH_CHECK();
+    return OFRI_OK;
 }
 
 // ---- updateFlow (.cl:408-429) -----------------------------------------------------------------------

@@ -539,6 +539,24 @@ def test_farneback_kernels_bit_exact_vs_oracle(ctx, shape):
 
 
 
+@pytest.mark.parametrize("shape", [(1, 1), (3, 5), (16, 64), (17, 65), (70, 130), (5, 300), (200, 9), (128, 256)])
+@pytest.mark.parametrize("polyN,ksh", [(7, 1), (5, 1), (7, 2)])
+def test_farneback_blur_polyexp_equals_its_steps(ctx, shape, polyN, ksh):
+    """Pre-blur and polynomial expansion in one call: the bits of ofri_fb_blur followed by ofri_fb_polyexp."""
+    import _ofri
+    from Farneback_PyCL import Farneback_PyCL
+    lib = _ofri.lib()
+    H, W = shape
+    rng = np.random.default_rng(H * 17 + W + polyN)
+    img = ctx.upload(rng.uniform(0, 255, shape).astype(np.float32))
+    fb = Farneback_PyCL(polyN=polyN)
+    fb.setPolynomialExpansionConsts()
+    fb.setGaussianBlurKernel(2 * ksh + 1, 0.0 if ksh == 1 else 1.1)
+    want = fb._polyexp(fb._blur(img, ksh)).numpy()
+    got = fb._blur_polyexp(img, ksh).numpy()
+    assert got.tobytes() == want.tobytes()
+
+
 @pytest.mark.parametrize("shape,ksh,box", [((70, 130), 16, 0), ((33, 64), 16, 1), ((40, 100), 7, 0), ((128, 256), 16, 0)])
 def test_farneback_fused_iteration_equals_its_steps(ctx, shape, ksh, box):
     """Window filter + updateFlow + updateMatrices in one call: the same bits as the three steps, with and without
