@@ -101,6 +101,28 @@ def test_hs_fast_mode_within_tolerance(ctx, fuse, alpha, nit, init):
     assert err == pytest.approx(float(h[key + "_err"]), rel=1e-4)
 
 
+@pytest.mark.parametrize("alpha", [1e-3, 0.05, 300.0, 1e5])
+def test_hs_fast_mode_over_the_range_of_alpha(ctx, alpha):
+    """The fast kernels scale the coefficients by 1/sqrt(alpha^2 + fx^2 + fy^2) once instead of dividing per sweep: the
+    tolerance must hold from a vanishing smoothness weight (the denominator is the squared gradient alone, zero where
+    the frames are flat) to one that swamps the data term."""
+    import HornSchunck as H
+    from oracle import hs
+    rng = np.random.default_rng(int(alpha * 1000) % 9973)
+    a = rng.uniform(0, 255, (96, 160)).astype(np.float32); b = rng.uniform(0, 255, (96, 160)).astype(np.float32)
+    a[40:56, 60:100] = 7.0; b[40:56, 60:100] = 7.0        # a flat patch: fx = fy = ft = 0 inside
+    z = np.zeros_like(a)
+    Ur, Vr, er = hs.hs(a, b, alpha, 25, z.copy(), z.copy())
+    for fuse in (0, 1):
+        ctx.set_hs_fuse(fuse)
+        try:
+            U, V, e = H.HS(a, b, alpha, 25, z.copy(), z.copy())
+        finally:
+            ctx.set_hs_fuse(0)
+        assert np.isfinite(U).all() and np.isfinite(V).all()
+        assert flow_rel(U, V, Ur, Vr) < 1e-5, (alpha, fuse)
+
+
 def test_hs_adapter_semantics(ctx):
     from HornSchunck import HSOpticalFlowAlgoAdapter
     h = load_gold("hs")
