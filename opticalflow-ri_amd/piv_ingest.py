@@ -144,20 +144,26 @@ class PairFeeder(object):
         except StopIteration:
             return
         slot = 0
-        while nxt is not None:
-            cur = nxt.result()                   # the worker is idle from here until the next submit
-            im0, im1 = self._widen(*cur)
-            # the staging slot we are about to refill was consumed by the widen kernels just enqueued:
-            # order the copy stream after them
-            slot ^= 1
-            try:
-                pair = next(it)
-                _ofri.check(_ofri.lib().ofri_ctx_wait(self.copy_ctx.handle, self.ctx.handle))
-                nxt = self._worker.submit(self._post, slot, pair)
-            except StopIteration:
+        try:
+            while nxt is not None:
+                cur = nxt.result()                   # the worker is idle from here until the next submit
                 nxt = None
-            yield im0, im1
-        self._worker.shutdown(wait=True)
+                im0, im1 = self._widen(*cur)
+                # the staging slot we are about to refill was consumed by the widen kernels just enqueued:
+                # order the copy stream after them
+                slot ^= 1
+                try:
+                    pair = next(it)
+                except StopIteration:
+                    pair = None
+                if pair is not None:
+                    _ofri.check(_ofri.lib().ofri_ctx_wait(self.copy_ctx.handle, self.ctx.handle))
+                    nxt = self._worker.submit(self._post, slot, pair)
+                yield im0, im1
+        finally:
+            # a consumer that stops early leaves an upload under way: let it finish before the buffers can go
+            self._worker.shutdown(wait=True)
+            self.copy_ctx.sync()
 
 
 class FlowDrain(object):

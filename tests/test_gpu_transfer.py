@@ -208,6 +208,13 @@ def test_stream_flows_overlaps_copies_and_keeps_bits(pair):
     for (U, V), (Ur, Vr) in zip(got, want):
         assert U.tobytes() == Ur.tobytes() and V.tobytes() == Vr.tobytes()
     assert list(stream_flows(ctx, iter([]), flow)) == []
+    # a consumer that stops after the first result leaves nothing behind that breaks the next stream
+    gen = stream_flows(ctx, iter(pairs), flow)
+    U, V = next(gen)
+    assert U.tobytes() == want[0][0].tobytes()
+    gen.close()
+    got = list(stream_flows(ctx, iter(pairs[:2]), flow))
+    assert got[1][1].tobytes() == want[1][1].tobytes()
     # the same from two alternating captured plans
     from piv_plan import StreamedPlan
     sp = StreamedPlan(I0.shape, 3.4, lambda: HSOpticalFlowAlgoAdapter([21, 45], 20), ctx=ctx, pyramidalLevels=2)
