@@ -473,14 +473,18 @@ def test_liushen_stopping_rule_and_tiny_shapes(ctx):
     np.testing.assert_array_equal(ud.numpy(), ur)
 
 
-def test_liushen_stops_at_every_iteration_count(ctx, pair):
+@pytest.mark.parametrize("big", [False, True])
+def test_liushen_stops_at_every_iteration_count(ctx, pair, big):
     """The stopping check of a sweep runs inside the next sweep's launch, which has then already started: whatever the
     count at which the rule is met (odd, even, the last allowed one), the result must be that sweep's, bit for bit,
     and the count the reference's loop would report."""
     import ctypes as C
     import _ofri
     lib = _ofri.lib()
-    I0, I1 = pair[0][100:230, 60:260].copy(), pair[1][100:230, 60:260].copy()
+    if big:
+        I0, I1 = np.tile(pair[0], (2, 2))[:1000, :1030].copy(), np.tile(pair[1], (2, 2))[:1000, :1030].copy()
+    else:
+        I0, I1 = pair[0][100:230, 60:260].copy(), pair[1][100:230, 60:260].copy()
     rows, cols = I0.shape
     a, b, z = ctx.upload(I0), ctx.upload(I1), ctx.zeros(I0.shape)
 
