@@ -382,6 +382,13 @@ def test_driver_accepts_foreign_adapter(ctx, pair):
     assert flow_rel(U, V, Ur, Vr) < 1e-5
     U2, V2 = Wrap(hs.HSAdapter([21, 45], 10), filter_sigma=3.4, pyr_levels=2).calculateFlow(I0, I1)
     np.testing.assert_array_equal(U, U2)
+    # the wrapper on frames that are already on the GPU
+    from HornSchunck import HSOpticalFlowAlgoAdapter
+    w = Wrap(HSOpticalFlowAlgoAdapter([21, 45, 21, 45], 10), filter_sigma=3.4, pyr_levels=2)
+    assert (w.pyr_levels, w.k_levels, w.filter_opt, w.warping, w.bi_linear) == (2, 1, None, True, True)
+    Uh, Vh = w.calculateFlow(I0, I1)
+    Ud, Vd = w.calculateFlowDevice(ctx.upload(I0), ctx.upload(I1))
+    np.testing.assert_array_equal(Ud.numpy(), Uh); np.testing.assert_array_equal(Vd.numpy(), Vh)
 
 
 # ------------------------------------------------------------------------------ full-size properties
