@@ -204,7 +204,9 @@ def main():
         groups = {}
         for r in full:
             # one sweep per launch; tile kernel: at most 8 per launch; row-streaming pipeline: 12 or 16
-            name = "k_hs_sweep" if r[2] == r[1] else ("k_hs_stream" if r[2] > 8 * r[1] else "k_hs_fused")
+            # (a last pipeline launch of 13 to 16 sweeps is another kernel instantiation and is timed on its own)
+            name = "k_hs_sweep" if r[2] == r[1] else ("k_hs_stream_deep" if r[2] > 12 * r[1] else
+                                                      ("k_hs_stream" if r[2] > 8 * r[1] else "k_hs_fused"))
             groups.setdefault(name, []).append(r)
         kname, grp = max(groups.items(), key=lambda kv: sum(r[0] for r in kv[1])) if groups else ("none", [])
         hs_ms_all = sum(r[0] for r in full)

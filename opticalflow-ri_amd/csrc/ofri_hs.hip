@@ -195,9 +195,11 @@ static int hs_stream_share(ofri_ctx *ctx, const void *const *ptrs, int nptrs, in
     if ((bits & 15) != 0 || (cols & 3) != 0 || cols < 8 || niter <= 0) return 0;
     if (ctx->hs_fuse == 16) return niter;
     const int per = ofri_hs_stream_sweeps();
-    // the left-over sweeps stay with the tile kernel: a pipeline launch costs the same for 1 to 12 sweeps (4 sweeps added to
-    // the flow so far at 4096 x 4096: 182 us against 189 us in the tile kernel; at 2048 x 2048: 56 against 38 us)
-    if (ctx->hs_fuse == 0 && ofri_hs_stream_pays(rows, cols) && niter >= 2 * per) return niter / per * per;
+    if (ctx->hs_fuse == 0 && ofri_hs_stream_pays(rows, cols) && niter >= 2 * per) {
+        // up to 4 left-over sweeps ride in a deeper last launch (hs_stream_path); more of them go to the tile kernel
+        const int rest = niter % per;
+        return rest <= ofri_hs_stream_deep_sweeps() - per ? niter : niter - rest;
+    }
     return 0;
 }
 
@@ -218,10 +220,20 @@ static int hs_stream_path(ofri_ctx *ctx, const float *Uin, const float *Vin, flo
     if (level) OFRI_TRY(ofri_sl_fill_level(ctx, set, first, second, level->U, level->V, level->taps_host, level->ntaps, a2, rows, cols));
     else OFRI_TRY(ofri_sl_fill(ctx, set, Uin, Vin, fx, fy, ft, first, second, a2, rows, cols));
     int rest = niter - n_stream, cur = 0, launches = 0;
+    // automatic mode: a last pipeline launch of 13 to 16 sweeps (timed on its own: it is another kernel)
+    const int per = ofri_hs_stream_sweeps(), odd = n_stream % per;
+    const int tail = (ctx->hs_fuse == 0 && n_stream > per && odd >= 1 && odd <= ofri_hs_stream_deep_sweeps() - per) ? per + odd : 0;
+    const int bulk = n_stream - tail;
     ofri_ctx::ProfRec rec{};
     OFRI_TRY(prof_begin(ctx, rec));
-    OFRI_TRY(ofri_sl_sweeps(ctx, set, n_stream, rest == 0, rest == 0 && accumulate, Uout, Vout, rows, cols, &cur, &launches));
-    OFRI_TRY(prof_end(ctx, rec, rows, cols, launches, n_stream));
+    OFRI_TRY(ofri_sl_sweeps(ctx, set, bulk, rest == 0 && tail == 0, rest == 0 && tail == 0 && accumulate, Uout, Vout, rows, cols, &cur, &launches));
+    OFRI_TRY(prof_end(ctx, rec, rows, cols, launches, bulk));
+    if (tail > 0) {
+        ofri_ctx::ProfRec rect{};
+        OFRI_TRY(prof_begin(ctx, rect));
+        OFRI_TRY(ofri_sl_sweeps(ctx, set, tail, rest == 0, rest == 0 && accumulate, Uout, Vout, rows, cols, &cur, &launches, true));
+        OFRI_TRY(prof_end(ctx, rect, rows, cols, launches, tail));
+    }
     if (rest > 0) {
         const int Tmax = ofri_hs_fused_max_sweeps(), L = (rest + Tmax - 1) / Tmax;
         ofri_ctx::ProfRec rec2{};

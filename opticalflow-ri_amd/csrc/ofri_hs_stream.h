@@ -12,13 +12,14 @@ struct OfriSlSet {
 };
 
 int ofri_hs_stream_sweeps(void);                       // sweeps per launch
+int ofri_hs_stream_deep_sweeps(void);                  // sweeps of the deeper launch that can take a tail (ofri_sl_sweeps, deep_tail)
 bool ofri_hs_stream_pays(int H, int W);                // field large enough for the pipeline to win
 size_t ofri_sl_bytes(int H, int W);                    // device bytes of a plane set
 void ofri_sl_layout(float *base, int H, int W, OfriSlSet *s);
 int ofri_sl_fill(ofri_ctx *ctx, OfriSlSet &s, const float *U, const float *V, const float *fx, const float *fy,
                  const float *ft, const float *first, const float *second, float a2, int H, int W);
 int ofri_sl_sweeps(ofri_ctx *ctx, OfriSlSet &s, int n, bool to_dense, bool accumulate, float *Uout, float *Vout,
-                   int H, int W, int *cur, int *launches);
+                   int H, int W, int *cur, int *launches, bool deep_tail = false);
 // Scaled coefficient planes (A, B, C) for the fast kernels outside a plane set: from dense fx, fy, ft, or
 // (fx == nullptr) differentiated from the two frames (first, second of computeDerivatives).  A, B, C may be fx, fy, ft.
 // pitch_out: row pitch of A, B, C in floats (0: dense).

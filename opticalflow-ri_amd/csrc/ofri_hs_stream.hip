@@ -22,18 +22,21 @@
 #define SL_RX 128                        // strip width (32 lanes x 4 pixels)
 #define SL_PF 6                          // rows the loader keeps in flight
 // The depth is a template parameter.  Built: NL = 12 sweeps per launch (three stage wavefronts + loader, 40 KB of LDS,
-// four workgroups per CU).  NL = 16 (four stage wavefronts + loader, 64 KB, two workgroups per CU) was measured at
-// 327 us per launch at 4096 x 4096 against 175 us for 12 sweeps: two workgroups per CU hide less of each other's waits.
+// four workgroups per CU) for the bulk, and NL = 16 (four stage wavefronts + loader, 52 KB, three workgroups per CU) for
+// a tail of 13 to 16 sweeps: 263 us per launch at 4096 x 4096 against 165 us for 12 sweeps, so 16.4 against 13.7 us per
+// sweep, but cheaper than a launch of 12 and a launch for the rest (with four coefficient planes and two workgroups per
+// CU it took 327 us).
 template <int NL> struct SlCfg {
     static constexpr int NS = NL / 2;                // pipeline stages (half-wavefronts)
     static constexpr int OX = SL_RX - 2 * NL;        // stored width: the sweeps eat NL columns on each side
     static constexpr int LAG = 3 * NS;               // the last stage's second sweep runs this many rows behind the loader
     static constexpr int CR = LAG;                   // coefficient ring rows: rows rho-(LAG-1) .. rho are live
     static constexpr int THREADS = NS * 32 + 64;
-    static constexpr int PER_CU = NL == 12 ? 4 : 2;  // workgroups per CU that the LDS (40 KB each at NL = 12) and 128 registers allow
+    static constexpr int PER_CU = NL == 12 ? 4 : 3;  // workgroups per CU that the LDS (40 KB each at NL = 12, 52 KB at 16) and 128 registers allow
     static constexpr int MIN_CHUNK = 128;            // chunk rows below which one workgroup per CU fewer is launched
 };
 #define SL_NL_MAIN 12
+#define SL_NL_DEEP 16
 
 __device__ __forceinline__ float sl_left(float v) {     // lane-1 (wave_shr:1)
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xF, 0xF, true));
@@ -280,6 +283,7 @@ __global__ void k_sl_coefs(const float *ca, const float *cb, const float *cc, fl
 }
 
 int ofri_hs_stream_sweeps(void) { return SL_NL_MAIN; }
+int ofri_hs_stream_deep_sweeps(void) { return SL_NL_DEEP; }
 // worth it where the row chunks are long against the pipeline's fill (2048 x 2048 pixels and up)
 bool ofri_hs_stream_pays(int H, int W) { return (long long)H * W >= 4000000LL && (W & 3) == 0; }
 
@@ -337,25 +341,29 @@ static void sl_launch(ofri_ctx *ctx, const SlPlanes &in, float *uo, float *vo, i
 // to_dense: the last launch stores into (Uout, Vout), adding to what they hold if accumulate; otherwise the result
 // stays in the set and *cur names its pair.
 int ofri_sl_sweeps(ofri_ctx *ctx, OfriSlSet &s, int n, bool to_dense, bool accumulate, float *Uout, float *Vout,
-                   int H, int W, int *cur, int *launches) {
+                   int H, int W, int *cur, int *launches, bool deep_tail) {
     // the loader addresses V, B as U, A plus one common plane stride
     OFRI_REQUIRE(s.V[0] - s.U[0] == s.V[1] - s.U[1] && s.fy - s.fx == s.V[0] - s.U[0] &&
                      s.V[0] > s.U[0] && (s.V[0] - s.U[0]) < (1LL << 29),
                  "plane set is not laid out as U V U V A B C");
     OFRI_REQUIRE((W & 3) == 0 && H >= 1 && W >= 4, "row-streaming pipeline needs a width that is a multiple of 4");
     OFRI_REQUIRE(to_dense || !accumulate, "only a dense destination can be accumulated into");
-    const int L = ceil_div(n, SL_NL_MAIN);
-    int remaining = n, c = *cur;
-    for (int k = 0; k < L; ++k) {
-        const int T = remaining < SL_NL_MAIN ? remaining : SL_NL_MAIN;
-        const bool dense = k == L - 1 && to_dense;
+    int remaining = n, c = *cur, L = 0;
+    while (remaining > 0) {
+        // deep_tail: when 13 to 16 sweeps are left, one launch of the 16-deep pipeline takes them (4096 x 4096: 263 us
+        // against 165 us for 12 sweeps plus a launch of 130 to 190 us for the rest)
+        const bool deep = deep_tail && remaining > SL_NL_MAIN && remaining <= SL_NL_DEEP;
+        const int T = deep ? remaining : (remaining < SL_NL_MAIN ? remaining : SL_NL_MAIN);
+        const bool dense = remaining == T && to_dense;
         SlPlanes in{s.U[c], s.V[c], s.fx, s.fy, s.ft};
         float *uo = dense ? Uout : s.U[c ^ 1], *vo = dense ? Vout : s.V[c ^ 1];
-        sl_launch<SL_NL_MAIN>(ctx, in, uo, vo, H, W, T, s.zero_in, dense && accumulate);
+        if (deep) sl_launch<SL_NL_DEEP>(ctx, in, uo, vo, H, W, T, s.zero_in, dense && accumulate);
+        else sl_launch<SL_NL_MAIN>(ctx, in, uo, vo, H, W, T, s.zero_in, dense && accumulate);
         OFRI_LAUNCH_CHECK();
         s.zero_in = 0;
         if (!dense) c ^= 1;
         remaining -= T;
+        ++L;
     }
     *cur = c;
     if (launches) *launches = L;

@@ -182,6 +182,27 @@ def test_hs_launch_shapes_agree_bitwise(ctx, shape, nit):
         np.testing.assert_array_equal(out[fuse][0], out[1][0]); np.testing.assert_array_equal(out[fuse][1], out[1][1])
 
 
+
+@pytest.mark.parametrize("nit", [24, 25, 27, 28, 29, 40])
+def test_hs_pipeline_tail_lengths_agree_bitwise(ctx, nit):
+    """On fields large enough for the row-streaming pipeline the automatic mode splits the sweeps into launches of 12,
+    a deeper last launch when 13 to 16 are left, and the tile kernel for other remainders: every split gives the bits of
+    one sweep per launch."""
+    from HornSchunck import hs_iterate_device
+    shape = (2048, 2052)
+    rng = np.random.default_rng(nit)
+    host = [rng.standard_normal(shape).astype(np.float32) for _ in range(5)]
+    out = {}
+    for fuse in (1, 0):
+        ctx.set_hs_fuse(fuse)
+        try:
+            d = [ctx.upload(x) for x in host]
+            hs_iterate_device(d[0], d[1], d[2], d[3], d[4], 3.0, nit)
+            out[fuse] = (d[0].numpy(), d[1].numpy())
+        finally:
+            ctx.set_hs_fuse(0)
+    assert out[0][0].tobytes() == out[1][0].tobytes() and out[0][1].tobytes() == out[1][1].tobytes()
+
 @pytest.mark.parametrize("shape,nit,zero", [((64, 96), 20, False), ((2048, 2048), 28, True), ((2048, 2052), 28, False),
                                             ((2048, 2048), 24, True), ((2048, 2048), 36, False)])
 def test_hs_accumulating_step_equals_step_plus_add(ctx, shape, nit, zero):
