@@ -141,6 +141,19 @@ int ofri_prof_read(ofri_ctx *ctx, int idx, float *ms, int *launches, int *sweeps
 int ofri_hs_compute(ofri_ctx *ctx, const float *frame0, const float *frame1,
                     const float *U_in, const float *V_in, float *U_out, float *V_out,
                     float alpha, int niter, int rows, int cols, double *err_host);
+/* ofri_hs_compute without any allocation.  No counterpart in the reference: it is for callers that cannot call
+ * hipMalloc (code under HIP graph capture, tight serving loops, harnesses that forbid it).  Same arguments, same
+ * kernels and same bits as ofri_hs_compute on the one-sweep and tile kernels; the scratch planes (two flow planes,
+ * three coefficient planes, padded copies for widths that are not a multiple of 4, a zero start, norm partials) live in
+ * a file-scope device array that every GPU holds until the process ends: 9 * OFRI_HS_STATIC_MAX_PIXELS floats + 16 KiB =
+ * 36 MiB per GPU.  rows * (cols rounded up to a multiple of 4) must not exceed OFRI_HS_STATIC_MAX_PIXELS, else
+ * OFRI_EINVAL.  Makes no hipMalloc / hipFree / pool call and creates no events (the ofri_prof_* records skip it).  All
+ * calls on one GPU share that GPU's array: calls that overlap on one GPU (two contexts, two threads) race; calls on
+ * one context are ordered by its stream. */
+#define OFRI_HS_STATIC_MAX_PIXELS (1 << 20)
+int ofri_hs_compute_static(ofri_ctx *ctx, const float *frame0, const float *frame1,
+                           const float *U_in, const float *V_in, float *U_out, float *V_out,
+                           float alpha, int niter, int rows, int cols, double *err_host);
 /* The same step as the driver uses it when no second algorithm refines the level: the new flow is an increment
  * that the driver adds to the flow accumulated so far (Uaccum += U, src/GenericPyramidalOpticalFlow.py:413-414).
  * U_acc, V_acc are updated in place with the same float32 additions; on large fields the last sweep launch does

@@ -63,6 +63,7 @@ _PROTOS = {
     "ofri_prof_count": ([_vp, C.POINTER(_i)], _i),
     "ofri_prof_read": ([_vp, _i, C.POINTER(_f), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)], _i),
     "ofri_hs_compute": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, C.POINTER(_d)], _i),
+    "ofri_hs_compute_static": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, C.POINTER(_d)], _i),
     "ofri_hs_compute_acc": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i], _i),
     "ofri_hs_level": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _i, _i], _i),
     "ofri_ls_compute": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _d, _i, _i, C.POINTER(_d), C.POINTER(_i)], _i),

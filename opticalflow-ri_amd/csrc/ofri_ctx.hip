@@ -33,6 +33,8 @@ extern "C" int ofri_device_count(int *count) {
     return OFRI_OK;
 }
 
+int ofri_hs_static_setup(int device);
+
 extern "C" int ofri_ctx_create(int device, void *stream, ofri_ctx **out) {
     OFRI_REQUIRE(out, "out is null");
     *out = nullptr;
@@ -41,6 +43,7 @@ extern "C" int ofri_ctx_create(int device, void *stream, ofri_ctx **out) {
         return ofri_set_error(OFRI_ENODEVICE, "no HIP device available (libofri_hip needs an AMD GPU; there is no CPU fallback)");
     OFRI_REQUIRE(device >= 0 && device < n, "device %d out of range (0..%d)", device, n - 1);
     OFRI_HIP(hipSetDevice(device));
+    OFRI_TRY(ofri_hs_static_setup(device));       // address of the allocation-free entry point's scratch array on this GPU
     ofri_ctx *c = new ofri_ctx();
     c->device = device;
     if (stream) {
@@ -427,16 +430,21 @@ static int ensure_red(ofri_ctx *ctx) {
 }
 
 double *ofri_red_slot(ofri_ctx *ctx, int slot);
-// device-side |a-b|_F into slot `slot` (0..63) of the context's result area; no host sync
-int ofri_norm_diff_dev(ofri_ctx *ctx, const float *a, const float *b, size_t n, int slot) {
-    OFRI_TRY(ensure_red(ctx));
+// device-side |a-b|_F into *out through the caller's RED_BLOCKS partial sums (both in device memory); no host sync
+int ofri_red_blocks(void) { return RED_BLOCKS; }
+int ofri_norm_diff_at(ofri_ctx *ctx, const float *a, const float *b, size_t n, double *partials, double *out) {
     int g = grid_for(n, 256);
     if (g > RED_BLOCKS) g = RED_BLOCKS;
-    k_sqdiff_partial<<<g, 256, 0, ctx->stream>>>(a, b, n, ctx->red_partials);
+    k_sqdiff_partial<<<g, 256, 0, ctx->stream>>>(a, b, n, partials);
     OFRI_LAUNCH_CHECK();
-    k_sum_final<<<1, 256, 0, ctx->stream>>>(ctx->red_partials, g, ctx->red_partials + RED_BLOCKS + slot, 1);
+    k_sum_final<<<1, 256, 0, ctx->stream>>>(partials, g, out, 1);
     OFRI_LAUNCH_CHECK();
     return OFRI_OK;
+}
+// the same into slot `slot` (0..63) of the context's result area
+int ofri_norm_diff_dev(ofri_ctx *ctx, const float *a, const float *b, size_t n, int slot) {
+    OFRI_TRY(ensure_red(ctx));
+    return ofri_norm_diff_at(ctx, a, b, n, ctx->red_partials, ctx->red_partials + RED_BLOCKS + slot);
 }
 int ofri_max_dev(ofri_ctx *ctx, const float *a, size_t n, int slot) {
     OFRI_TRY(ensure_red(ctx));
@@ -449,11 +457,15 @@ int ofri_max_dev(ofri_ctx *ctx, const float *a, size_t n, int slot) {
     return OFRI_OK;
 }
 double *ofri_red_slot(ofri_ctx *ctx, int slot) { return ctx->red_partials + RED_BLOCKS + slot; }
-int ofri_read_slots(ofri_ctx *ctx, int first, int count, double *out_host) {
-    OFRI_HIP(hipMemcpyAsync(ctx->pinned, ofri_red_slot(ctx, first), count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+// count (<= 512) doubles from device memory to the host through the context's pinned buffer; waits for the stream
+int ofri_read_doubles(ofri_ctx *ctx, const double *dev, int count, double *out_host) {
+    OFRI_HIP(hipMemcpyAsync(ctx->pinned, dev, count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     OFRI_TRY(ofri_stream_wait(ctx));
     memcpy(out_host, ctx->pinned, count * sizeof(double));
     return OFRI_OK;
+}
+int ofri_read_slots(ofri_ctx *ctx, int first, int count, double *out_host) {
+    return ofri_read_doubles(ctx, ofri_red_slot(ctx, first), count, out_host);
 }
 
 extern "C" int ofri_norm_diff(ofri_ctx *ctx, const float *a, const float *b, size_t n, double *out_host) {

@@ -6,6 +6,9 @@
 
 int ofri_norm_diff_dev(ofri_ctx *ctx, const float *a, const float *b, size_t n, int slot);
 int ofri_read_slots(ofri_ctx *ctx, int first, int count, double *out_host);
+int ofri_norm_diff_at(ofri_ctx *ctx, const float *a, const float *b, size_t n, double *partials, double *out);
+int ofri_read_doubles(ofri_ctx *ctx, const double *dev, int count, double *out_host);
+int ofri_red_blocks(void);
 
 // ---------------------------------------------------------------------------------------------
 // Derivatives (formula and citation: hs_derivs_at in ofri_hs_math.h).
@@ -256,12 +259,13 @@ static int hs_stream_path(ofri_ctx *ctx, const float *Uin, const float *Vin, flo
 // is 16-byte aligned and a strip that straddles the right edge has room for its last columns), seven planes in one
 // block: two U/V pairs and the scaled coefficients.  Same arguments as hs_iterate_io; niter > 0.
 static int hs_iterate_padded(ofri_ctx *ctx, const float *Uin, const float *Vin, float *Uout, float *Vout, const float *fx,
-                             const float *fy, const float *ft, float a2, int niter, int rows, int cols, bool frames) {
+                             const float *fy, const float *ft, float a2, int niter, int rows, int cols, bool frames,
+                             float *work = nullptr) {
     const int P = (cols + 3) & ~3;
     const size_t plane = (size_t)rows * P, wbytes = (size_t)cols * sizeof(float), pbytes = (size_t)P * sizeof(float);
     PoolBuf buf(ctx);
-    OFRI_TRY(buf.get(7 * plane * sizeof(float)));
-    float *base = buf.as<float>();
+    if (!work) OFRI_TRY(buf.get(7 * plane * sizeof(float)));
+    float *base = work ? work : buf.as<float>();
     float *U[2] = {base, base + 2 * plane}, *V[2] = {base + plane, base + 3 * plane};
     float *A = base + 4 * plane, *B = base + 5 * plane, *C = base + 6 * plane;
     OFRI_REQUIRE((((size_t)base) & 15) == 0, "pool block is not 16-byte aligned");
@@ -289,8 +293,11 @@ static int hs_iterate_padded(ofri_ctx *ctx, const float *Uin, const float *Vin, 
 // niter sweeps from (Uin, Vin) into (Uout, Vout); Uin/Vin may alias Uout/Vout.  Launches ping-pong between
 // the output planes and two pooled scratch planes, arranged so that the last launch lands in the output.
 // frames: (fx, fy) are the two images computeDerivatives takes and ft is a spare plane; the coefficients are made here.
+// work: null (scratch planes come from the context's pool), or caller-provided scratch of 7 * rows * ((cols + 3) & ~3)
+// floats, 16-byte aligned; with it the call allocates nothing and stays on the one-sweep and tile kernels (same bits).
 static int hs_iterate_io(ofri_ctx *ctx, const float *Uin, const float *Vin, float *Uout, float *Vout, const float *fx,
-                         const float *fy, const float *ft, float alpha, int niter, int rows, int cols, bool frames = false) {
+                         const float *fy, const float *ft, float alpha, int niter, int rows, int cols, bool frames = false,
+                         float *work = nullptr) {
     const size_t bytes = (size_t)rows * cols * sizeof(float);
     if (niter == 0) {
         if (Uin != Uout) OFRI_HIP(hipMemcpyAsync(Uout, Uin, bytes, hipMemcpyDeviceToDevice, ctx->stream));
@@ -299,25 +306,32 @@ static int hs_iterate_io(ofri_ctx *ctx, const float *Uin, const float *Vin, floa
     }
     const float a2 = alpha * alpha;         // alpha is a float32 in the reference's compiled signature
     const bool exact = ctx->hs_fuse == -1;  // -1: bit-exact restatement of scipy's float64 accumulation
-    if (!frames) {
+    if (!frames && !work) {
         const void *q[7] = {Uin, Vin, Uout, Vout, fx, fy, ft};
         const int n_stream = hs_stream_share(ctx, q, 7, niter, rows, cols);
         if (n_stream > 0)
             return hs_stream_path(ctx, Uin, Vin, Uout, Vout, fx, fy, ft, nullptr, nullptr, a2, niter, n_stream, rows, cols);
     }
     if (!exact && ctx->hs_fuse != 1 && (cols & 3) != 0 && cols >= 16 && rows >= 16)
-        return hs_iterate_padded(ctx, Uin, Vin, Uout, Vout, fx, fy, ft, a2, niter, rows, cols, frames);
+        return hs_iterate_padded(ctx, Uin, Vin, Uout, Vout, fx, fy, ft, a2, niter, rows, cols, frames, work);
     PoolBuf tu(ctx), tv(ctx), ca(ctx), cb(ctx), cc(ctx);
-    OFRI_TRY(tu.get(bytes));
-    OFRI_TRY(tv.get(bytes));
-    OFRI_TRY(ca.get(bytes)); OFRI_TRY(cb.get(bytes)); OFRI_TRY(cc.get(bytes));
-    if (exact) {
-        if (frames) OFRI_TRY(ofri_hs_derivs(ctx, fx, fy, ca.as<float>(), cb.as<float>(), cc.as<float>(), rows, cols));
-    } else {                                 // the fast kernels work on the scaled coefficients
-        OFRI_TRY(ofri_hs_scaled_coefs(ctx, frames ? nullptr : fx, fy, ft, fx, fy, ca.as<float>(), cb.as<float>(), cc.as<float>(), a2, rows, cols));
+    float *wp[5];                            // two flow planes, three coefficient planes
+    if (work) {
+        const size_t stride = ((size_t)rows * cols + 3) & ~(size_t)3;
+        for (int k = 0; k < 5; ++k) wp[k] = work + k * stride;
+    } else {
+        OFRI_TRY(tu.get(bytes));
+        OFRI_TRY(tv.get(bytes));
+        OFRI_TRY(ca.get(bytes)); OFRI_TRY(cb.get(bytes)); OFRI_TRY(cc.get(bytes));
+        wp[0] = tu.as<float>(); wp[1] = tv.as<float>(); wp[2] = ca.as<float>(); wp[3] = cb.as<float>(); wp[4] = cc.as<float>();
     }
-    if (frames || !exact) { fx = ca.as<float>(); fy = cb.as<float>(); ft = cc.as<float>(); }
-    const void *ptrs[9] = {Uin, Vin, Uout, Vout, fx, fy, ft, tu.p, tv.p};
+    if (exact) {
+        if (frames) OFRI_TRY(ofri_hs_derivs(ctx, fx, fy, wp[2], wp[3], wp[4], rows, cols));
+    } else {                                 // the fast kernels work on the scaled coefficients
+        OFRI_TRY(ofri_hs_scaled_coefs(ctx, frames ? nullptr : fx, fy, ft, fx, fy, wp[2], wp[3], wp[4], a2, rows, cols));
+    }
+    if (frames || !exact) { fx = wp[2]; fy = wp[3]; ft = wp[4]; }
+    const void *ptrs[9] = {Uin, Vin, Uout, Vout, fx, fy, ft, wp[0], wp[1]};
     const bool fused = !exact && ctx->hs_fuse != 1 && ofri_hs_fused_ok(ptrs, 9, rows, cols);
     int Tmax = 1;
     if (fused) {
@@ -335,7 +349,7 @@ static int hs_iterate_io(ofri_ctx *ctx, const float *Uin, const float *Vin, floa
     int remaining = niter;
     for (int k = 0; k < L; ++k) {
         const bool to_out = detour ? ((L - k) % 2 == 0) : ((L - 1 - k) % 2 == 0);
-        float *du = to_out ? Uout : tu.as<float>(), *dv = to_out ? Vout : tv.as<float>();
+        float *du = to_out ? Uout : wp[0], *dv = to_out ? Vout : wp[1];
         const int T = remaining < Tmax ? remaining : Tmax;
         if (fused) OFRI_TRY(ofri_hs_fused_launch(ctx, su, sv, du, dv, fx, fy, ft, T, rows, cols));
         else if (exact) OFRI_TRY(hs_sweep_launch<true>(ctx, su, sv, fx, fy, ft, du, dv, a2, rows, cols));
@@ -360,40 +374,108 @@ extern "C" int ofri_hs_iterate(ofri_ctx *ctx, float *U, float *V, const float *f
     return hs_iterate_io(ctx, U, V, U, V, fx, fy, ft, alpha, niter, rows, cols);
 }
 
-extern "C" int ofri_hs_compute(ofri_ctx *ctx, const float *frame0, const float *frame1,
-                               const float *U_in, const float *V_in, float *U_out, float *V_out,
-                               float alpha, int niter, int rows, int cols, double *err_host) {
-    OFRI_TRY(ofri_check_ctx(ctx));
+// ofri_hs_compute; work: null, or the scratch of an allocation-free call: 9 * rows * ((cols + 3) & ~3) floats (two zero
+// planes for a null start, then hs_iterate_io's seven) and red: ofri_red_blocks() + 2 doubles for the error norms.
+static int hs_compute_impl(ofri_ctx *ctx, const float *frame0, const float *frame1, const float *U_in, const float *V_in,
+                           float *U_out, float *V_out, float alpha, int niter, int rows, int cols, double *err_host,
+                           float *work, double *red) {
     OFRI_REQUIRE(frame0 && frame1 && U_out && V_out, "null pointer");
     OFRI_REQUIRE((U_in == nullptr) == (V_in == nullptr), "U_in and V_in must both be given or both be null");
     OFRI_REQUIRE(U_out != U_in && V_out != V_in && U_out != V_out, "output must not alias input");
     OFRI_REQUIRE(rows > 0 && cols > 0 && niter >= 0, "bad shape or niter");
     size_t n = (size_t)rows * cols, bytes = n * sizeof(float);
+    const size_t wplane = (size_t)rows * ((cols + 3) & ~3);
     // HS(im2=frame0, im1=frame1) -> computeDerivatives(im1=frame1, im2=frame0)   (HornSchunck.py:37,73,84)
     const void *q[6] = {frame0, frame1, U_in, V_in, U_out, V_out};
-    const int n_stream = hs_stream_share(ctx, q, 6, niter, rows, cols);
+    const int n_stream = work ? 0 : hs_stream_share(ctx, q, 6, niter, rows, cols);
     PoolBuf zu(ctx), zv(ctx);
     if (!U_in && (n_stream == 0 || err_host)) {       // a zero start that somebody has to read: make it
-        OFRI_TRY(zu.get(bytes)); OFRI_TRY(zv.get(bytes));
-        OFRI_HIP(hipMemsetAsync(zu.p, 0, bytes, ctx->stream));
-        OFRI_HIP(hipMemsetAsync(zv.p, 0, bytes, ctx->stream));
-        U_in = zu.as<float>(); V_in = zv.as<float>();
+        float *z0, *z1;
+        if (work) { z0 = work; z1 = work + wplane; }
+        else { OFRI_TRY(zu.get(bytes)); OFRI_TRY(zv.get(bytes)); z0 = zu.as<float>(); z1 = zv.as<float>(); }
+        OFRI_HIP(hipMemsetAsync(z0, 0, bytes, ctx->stream));
+        OFRI_HIP(hipMemsetAsync(z1, 0, bytes, ctx->stream));
+        U_in = z0; V_in = z1;
     }
     if (n_stream > 0) {
         // large field: the derivatives go straight into the pipeline's plane set; a zero start is not materialised
         OFRI_TRY(hs_stream_path(ctx, U_in, V_in, U_out, V_out, nullptr, nullptr, nullptr, frame1, frame0, alpha * alpha, niter,
                                 n_stream, rows, cols));
     } else {
-        OFRI_TRY(hs_iterate_io(ctx, U_in, V_in, U_out, V_out, frame1, frame0, nullptr, alpha, niter, rows, cols, true));
+        OFRI_TRY(hs_iterate_io(ctx, U_in, V_in, U_out, V_out, frame1, frame0, nullptr, alpha, niter, rows, cols, true,
+                               work ? work + 2 * wplane : nullptr));
     }
     if (err_host) {
-        OFRI_TRY(ofri_norm_diff_dev(ctx, U_out, U_in, n, 0));
-        OFRI_TRY(ofri_norm_diff_dev(ctx, V_out, V_in, n, 1));
         double r[2];
-        OFRI_TRY(ofri_read_slots(ctx, 0, 2, r));
+        if (red) {
+            const int nb = ofri_red_blocks();
+            OFRI_TRY(ofri_norm_diff_at(ctx, U_out, U_in, n, red, red + nb));
+            OFRI_TRY(ofri_norm_diff_at(ctx, V_out, V_in, n, red, red + nb + 1));
+            OFRI_TRY(ofri_read_doubles(ctx, red + nb, 2, r));
+        } else {
+            OFRI_TRY(ofri_norm_diff_dev(ctx, U_out, U_in, n, 0));
+            OFRI_TRY(ofri_norm_diff_dev(ctx, V_out, V_in, n, 1));
+            OFRI_TRY(ofri_read_slots(ctx, 0, 2, r));
+        }
         *err_host = (r[0] + r[1]) / ((double)rows * (double)cols);
     }
     return OFRI_OK;
+}
+
+extern "C" int ofri_hs_compute(ofri_ctx *ctx, const float *frame0, const float *frame1,
+                               const float *U_in, const float *V_in, float *U_out, float *V_out,
+                               float alpha, int niter, int rows, int cols, double *err_host) {
+    OFRI_TRY(ofri_check_ctx(ctx));
+    return hs_compute_impl(ctx, frame0, frame1, U_in, V_in, U_out, V_out, alpha, niter, rows, cols, err_host, nullptr, nullptr);
+}
+
+// ---------------------------------------------------------------------------------------------
+// ofri_hs_compute for callers that must not allocate: every scratch plane lives in one file-scope device array.
+// Each GPU the library runs on holds its own copy of the array (at its own address) until the process ends; the host
+// only ever uses the per-device address looked up once in ofri_hs_static_setup, never the array's name.
+#define HS_STATIC_RED_BYTES 16384           /* ofri_red_blocks() + 2 doubles, rounded up */
+#define HS_STATIC_BYTES (HS_STATIC_RED_BYTES + 9 * (size_t)OFRI_HS_STATIC_MAX_PIXELS * sizeof(float))
+static __device__ __align__(256) unsigned char scratch[HS_STATIC_BYTES];
+
+#define HS_STATIC_MAX_DEVICES 64
+static void *g_static_ptr[HS_STATIC_MAX_DEVICES];
+static std::mutex g_static_mu;
+
+// Once per device, with that device current (ofri_ctx_create calls this before it makes the context).
+int ofri_hs_static_setup(int device) {
+    OFRI_REQUIRE(device >= 0 && device < HS_STATIC_MAX_DEVICES, "device %d beyond the %d this library tracks", device, HS_STATIC_MAX_DEVICES);
+    std::lock_guard<std::mutex> lock(g_static_mu);
+    if (g_static_ptr[device]) return OFRI_OK;
+    void *p = nullptr;
+    OFRI_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    OFRI_REQUIRE(p && (((size_t)p) & 255) == 0, "scratch array of device %d has no usable address", device);
+    OFRI_REQUIRE((size_t)(ofri_red_blocks() + 2) * sizeof(double) <= HS_STATIC_RED_BYTES, "reduction area too small");
+    g_static_ptr[device] = p;
+    return OFRI_OK;
+}
+
+extern "C" int ofri_hs_compute_static(ofri_ctx *ctx, const float *frame0, const float *frame1, const float *U_in,
+                                      const float *V_in, float *U_out, float *V_out, float alpha, int niter, int rows,
+                                      int cols, double *err_host) {
+    OFRI_TRY(ofri_check_ctx(ctx));
+    OFRI_REQUIRE(rows > 0 && cols > 0, "bad shape %d x %d", rows, cols);
+    const size_t wplane = (size_t)rows * (((size_t)cols + 3) & ~(size_t)3);
+    OFRI_REQUIRE(wplane <= (size_t)OFRI_HS_STATIC_MAX_PIXELS,
+                 "ofri_hs_compute_static: %d x %d needs %zu pixels per scratch plane, the limit is %d "
+                 "(rows x columns rounded up to a multiple of 4); use ofri_hs_compute for larger fields",
+                 rows, cols, wplane, OFRI_HS_STATIC_MAX_PIXELS);
+    unsigned char *base;
+    {
+        std::lock_guard<std::mutex> lock(g_static_mu);
+        base = static_cast<unsigned char *>(ctx->device < HS_STATIC_MAX_DEVICES ? g_static_ptr[ctx->device] : nullptr);
+    }
+    OFRI_REQUIRE(base, "no scratch address for device %d", ctx->device);
+    const bool prof = ctx->prof;            // the timing records create events: not in a call that allocates nothing
+    ctx->prof = false;
+    const int rc = hs_compute_impl(ctx, frame0, frame1, U_in, V_in, U_out, V_out, alpha, niter, rows, cols, err_host,
+                                   reinterpret_cast<float *>(base + HS_STATIC_RED_BYTES), reinterpret_cast<double *>(base));
+    ctx->prof = prof;
+    return rc;
 }
 
 extern "C" int ofri_hs_compute_acc(ofri_ctx *ctx, const float *frame0, const float *frame1, const float *U_in,
