@@ -8,6 +8,10 @@ N > 1 every pair's flow field is gathered to rank 0 over RCCL, overlapped with t
 
     python bench.py --gpus 1 --steps 10 --warmup 2
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+``--batch P`` measures the batch configuration instead: P independent 2048x2048 pairs (``--size``), Horn-Schunck
+plus Liu-Shen per pair, sharded in contiguous blocks over the ranks, flow fields gathered to rank 0 per chunk
+(piv_batch.run_batch); one step = the whole batch, reported with and without the gather.
 """
 import argparse
 import json
@@ -21,7 +25,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "opticalflow-ri_amd")]
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak
-HS_BYTES_PER_PX_SWEEP = 28.0   # read U,V,fx,fy,ft + write U,V, float32
+HS_BYTES_PER_PX_SWEEP = 28.0   # one Jacobi sweep: read U,V and three coefficient planes + write U,V, float32
+VALU_LANE_OPS_PER_S = 256 * 4 * 16 * 2.4e9      # 256 CUs x 4 SIMDs x 16 lanes per clock x 2.4 GHz, non-packed fp32
+HS_OPS_PER_PX_SWEEP = 14       # vector operations per pixel and sweep of the fast kernels (ofri_hs_math.h)
 
 
 def parse():
@@ -29,10 +35,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--size", type=int, default=4096, help="frame edge in pixels (benchmark config: 4096)")
+    ap.add_argument("--size", type=int, default=None, help="frame edge in pixels (headline: 4096; with --batch: 2048)")
     ap.add_argument("--niter", type=int, default=100)
     ap.add_argument("--fuse", type=int, default=0, help="Jacobi sweeps per launch (0 = automatic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-one-core-only", action="store_true", help="skip the all-cores leg of the CPU baseline")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--same-device", action="store_true", help="all ranks compute on GPU 0 (rehearsal on a one-GPU box)")
@@ -44,23 +51,215 @@ def parse():
     ap.add_argument("--graph", action="store_true", help="replay the pair's launches from a captured HIP graph (piv_plan.FlowPlan)")
     ap.add_argument("--in-flight", type=int, default=1, help="with --graph: pairs per step, each on its own context/stream "
                     "(small frames do not fill the GPU one pair at a time)")
-    return ap.parse_args()
+    ap.add_argument("--batch", type=int, default=0, help="total number of pairs of the batch configuration (512 on 8 GPUs); 0 = headline")
+    ap.add_argument("--chunk", type=int, default=8, help="with --batch: pairs per gather")
+    ap.add_argument("--distinct", type=int, default=4, help="with --batch: distinct synthetic pairs generated per rank (cycled; "
+                    "rendering one 2048x2048 pair takes 0.5 s of host time)")
+    a = ap.parse_args()
+    if a.size is None:
+        a.size = 2048 if a.batch else 4096
+    return a
 
 
-def cpu_baseline(niter, n=2048, pairs=2):
-    """The CPU oracle (NumPy/SciPy restatement of the reference's Numba/SciPy path, single thread) on a
-    bounded sample of the same workload: the identical pipeline on two 2048x2048 synthetic pairs
-    (each a quarter of the benchmark frame; the per-pixel cost of the CPU path does not depend on the size)."""
+# ------------------------------------------------------------------------------------------ CPU baseline
+def _cpu_pair(args):
+    """One pair through the CPU oracle; returns seconds (also the worker of the all-cores leg)."""
+    n, niter, seed = args
     from piv_synth import synth_piv
     from oracle import hs as ohs, pyramid as opyr
-    frames = [tuple(f.astype(np.float32) for f in synth_piv(n, n, seed=k)) for k in range(pairs)]
+    a, b = (f.astype(np.float32) for f in synth_piv(n, n, seed=seed))
     t = time.perf_counter()
-    for a, b in frames:
-        opyr.pyramidal_flow(a, b, 3.4, ohs.HSAdapter([21, 45], niter), 2, 1, None)
-    dt = time.perf_counter() - t
-    return {"value": pairs * n * n / dt / 1e6, "unit": "Mpix/s", "cores": 1, "kind": "port",
-            "sample": "same 2-level HS pipeline (Fs3.4, alphas [21,45], %d sweeps/level) on %d %dx%d synthetic pairs, "
-                      "%.1f s, NumPy/SciPy single thread" % (niter, pairs, n, n, dt)}
+    opyr.pyramidal_flow(a, b, 3.4, ohs.HSAdapter([21, 45], niter), 2, 1, None)
+    return time.perf_counter() - t
+
+
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(niter, all_cores=True, n=2048):
+    """The CPU oracle (NumPy/SciPy restatement of the reference's Numba/SciPy path; the timed loop is the reference's
+    HS_helper, src/HornSchunck.py:62-71, plus the pyramid glue around it) on a bounded sample of the same workload:
+    the identical pipeline on 2048x2048 synthetic pairs (a quarter of the benchmark frame; the per-pixel cost of
+    the CPU path does not depend on the size - checked by one run at 4096x4096), single thread: median of three.
+    All-cores leg: one such pair per worker process on min(16, nproc) cores at once (the reference itself is
+    single-threaded; this is what a user gets by running independent pairs side by side)."""
+    times = sorted(_cpu_pair((n, niter, k)) for k in range(3))
+    med = times[1]
+    t_full = _cpu_pair((4096, niter, 0))
+    out = {"value": n * n / med / 1e6, "unit": "Mpix/s", "cores": 1, "kind": "port",
+           "cpu_model": _cpu_model(), "nproc": os.cpu_count(),
+           "runs_s": [round(t, 3) for t in times], "value_4096_single_run": 4096 * 4096 / t_full / 1e6,
+           "sample": "same 2-level HS pipeline (Fs3.4, alphas [21,45], %d sweeps/level), NumPy/SciPy single thread: median of "
+                     "3 runs on %dx%d synthetic pairs (%.1f s each), plus one 4096x4096 pair (%.1f s)" % (niter, n, n, med, t_full)}
+    if all_cores:
+        try:
+            import multiprocessing as mp
+            cores = max(1, min(16, os.cpu_count() or 1))
+            with mp.get_context("spawn").Pool(cores) as pool:
+                pool.map(_cpu_pair, [(256, 2, 0)] * cores)               # start the workers, import NumPy/SciPy
+                t = time.perf_counter()
+                pool.map(_cpu_pair, [(n, niter, 100 + k) for k in range(cores)], chunksize=1)
+                dt = time.perf_counter() - t
+            out["all_cores"] = {"value": cores * n * n / dt / 1e6, "unit": "Mpix/s", "cores": cores,
+                                "sample": "%d worker processes, one %dx%d pair each, %.1f s" % (cores, n, n, dt)}
+        except Exception as e:                                           # the single-thread figure stands on its own
+            out["all_cores"] = {"error": repr(e)}
+    return out
+
+
+# ------------------------------------------------------------------------------------------ roofline block
+def _committed(name):
+    try:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return {}
+
+
+def one_sweep_roofline(ctx, H, W, launches=20):
+    """The plain one-sweep-per-launch kernel (k_hs_sweep_vec4) on the same field: the HBM-bound form of the update,
+    28 B per pixel and launch, timed with the library's events on the context's stream."""
+    import _ofri
+    lib = _ofri.lib()
+    planes = [ctx.zeros((H, W)) for _ in range(5)]
+    ctx.set_hs_fuse(1)
+    try:
+        args = [p.ptr for p in planes] + [21.0]
+        _ofri.check(lib.ofri_hs_iterate(ctx.handle, *args, 4, H, W))
+        ctx.sync()
+        ctx.prof_enable(True)
+        _ofri.check(lib.ofri_hs_iterate(ctx.handle, *args, launches, H, W))
+        recs = ctx.prof_records()
+        ctx.prof_enable(False)
+    finally:
+        ctx.set_hs_fuse(0)
+    ms = sum(r[0] for r in recs) / max(1, sum(r[1] for r in recs))
+    gbs = HS_BYTES_PER_PX_SWEEP * H * W / (ms * 1e-3) / 1e9
+    return {"kernel": "k_hs_sweep_vec4@%dx%d" % (H, W), "bound": "hbm", "launch_ms": ms, "achieved": gbs,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "launches_timed": launches}
+
+
+def roofline_block(recs, H, W, steps, ms_per_step):
+    """Dominant kernel = the Jacobi sweep launches of the full-resolution level.  A Horn-Schunck call may use several
+    kernels there (row-streaming pipeline for the multiples of 12 sweeps, a deeper launch or the tile kernel for the
+    rest); the one with the largest share of the time is reported."""
+    full = [r for r in recs if r[3] == H and r[4] == W]
+    groups = {}
+    for r in full:
+        # one sweep per launch; tile kernel: at most 8 per launch; row-streaming pipeline: 12 (a last launch of 13 to 16
+        # sweeps is another kernel instantiation and is timed on its own)
+        name = "k_hs_sweep" if r[2] == r[1] else ("k_hs_stream_deep" if r[2] > 12 * r[1] else
+                                                  ("k_hs_stream" if r[2] > 8 * r[1] else "k_hs_fused"))
+        groups.setdefault(name, []).append(r)
+    if not groups:
+        return None
+    kname, grp = max(groups.items(), key=lambda kv: sum(r[0] for r in kv[1]))
+    hs_ms_all = sum(r[0] for r in full)
+    ms = sum(r[0] for r in grp)
+    launches = sum(r[1] for r in grp)
+    sweeps = sum(r[2] for r in grp)
+    launch_ms = ms / max(launches, 1)
+    spl = sweeps / max(launches, 1)
+    key = "%s@%dx%d" % (kname, H, W)
+    blocked = spl > 1.5
+    # HBM roofline of the launch: the bytes one launch has to move whatever it does on chip (every plane read once,
+    # the flow written once).  For a one-sweep kernel this equals the per-sweep figure.
+    alg_launch = HS_BYTES_PER_PX_SWEEP * H * W
+    achieved = alg_launch / (launch_ms * 1e-3) / 1e9
+    traffic = _committed("pmc_traffic.json").get(key)              # HBM bytes per launch from the committed PMC passes
+    sq = _committed("pmc_sq.json").get(key)                         # issue fractions from the committed SQ pass
+    useful = HS_OPS_PER_PX_SWEEP * H * W * spl / VALU_LANE_OPS_PER_S * 1e3          # ms of vector issue the sweeps need
+    block = {
+        "bound": "valu-issue" if blocked else "hbm",
+        "kernel": key, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+        "traffic": traffic, "launch_ms": launch_ms, "launches_timed": launches, "sweeps_per_launch": spl,
+        "algorithmic_bytes_per_launch": alg_launch,
+        "hbm_frac_measured": (traffic / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+        # the same launch against the per-sweep byte model (what separate sweeps would have to move): above the HBM
+        # peak by construction when sweeps are blocked on chip; not a roofline fraction
+        "effective_per_sweep_GBs": HS_BYTES_PER_PX_SWEEP * H * W * spl / (launch_ms * 1e-3) / 1e9,
+        "valu_useful_issue_frac": useful / launch_ms if launch_ms > 0 else None,
+        "valu_issue_measured": sq,
+        "kernel_share_of_step": (ms / steps) / ms_per_step if ms_per_step > 0 else None,
+        "hs_full_level_share_of_step": (hs_ms_all / steps) / ms_per_step if ms_per_step > 0 else None,
+    }
+    return block
+
+
+# ------------------------------------------------------------------------------------------ batch configuration
+def run_batch_config(args, rank, world, local, dist, torch):
+    """The 512-pair configuration at any pair count: contiguous blocks per rank, Horn-Schunck + Liu-Shen per pair from a
+    captured graph, frames resident in HBM as uint8, one asynchronous gather per chunk.  Timed twice: with the gather
+    (the job as specified) and without it."""
+    import piv_batch
+    from piv_synth import synth_piv
+    H = W = args.size
+    dev = 0 if args.same_device else local
+    ctx, stream = piv_batch.torch_context(dev)
+    a, b = piv_batch.partition(args.batch, world)[rank]
+    distinct = max(1, min(args.distinct, max(b - a, 1)))
+    resident = []
+    for k in range(distinct):
+        f0, f1 = synth_piv(H, W, seed=a + k)
+        resident.append((ctx.upload(f0, np.uint8), ctx.upload(f1, np.uint8)))
+    flow = piv_batch.hs_liushen_flow(ctx, (H, W), niter=args.niter, graph=True)
+    pair_fn = lambda p: resident[(p - a) % distinct]
+
+    def sync_all():
+        ctx.sync()
+        if dist is not None:
+            if args.backend == "nccl":
+                torch.cuda.synchronize()
+            dist.barrier()
+            if args.backend == "nccl":
+                torch.cuda.synchronize()
+
+    def timed(gather, steps):
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = piv_batch.run_batch(args.batch, pair_fn, flow, ctx=ctx, chunk=args.chunk, gather=gather, shape=(H, W))
+        sync_all()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            dt = piv_batch.max_over_ranks(dt, device="cuda" if args.backend == "nccl" else None)
+        return dt, out
+
+    for _ in range(args.warmup):
+        piv_batch.run_batch(min(args.batch, world * args.chunk), lambda p: resident[0], flow, ctx=ctx, chunk=args.chunk,
+                            gather=dist is not None and not args.no_gather, shape=(H, W))
+    dt_g, out = timed(not args.no_gather, args.steps)
+    ok = None
+    if rank == 0 and out is not None:
+        ok = bool(tuple(out.shape) == (args.batch, 2, H, W)) if (dist is not None and not args.no_gather) else True
+    del out
+    dt_n, _ = timed(False, args.steps)
+    if rank != 0:
+        return None
+    px = args.batch * H * W * args.steps
+    return {
+        "metric": "Mpix/s per PIV frame pair (batch of %d pairs, HS + Liu-Shen)" % args.batch,
+        "value": px / dt_g / 1e6, "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt_g / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic (%d distinct pairs per rank, cycled)" % distinct,
+        "config": {"workload": "batch of %d independent %dx%d synthetic pairs, HS Fs3.4 2-level alphas [21,45] %d sweeps/level + "
+                               "Liu-Shen h=5 Fs_opt 0.48 on every level, contiguous blocks per rank" % (args.batch, H, W, args.niter),
+                   "pairs_per_gpu": [q - p for p, q in piv_batch.partition(args.batch, world)],
+                   "flow_gather": ("none" if (dist is None or args.no_gather) else
+                                   "%s gather to rank 0 every %d pairs, overlapped with the next chunk" %
+                                   ("rccl" if args.backend == "nccl" else args.backend, args.chunk)),
+                   "captured_graph": True, "gathered_shape_ok": ok},
+        "without_gather": {"value": px / dt_n / 1e6, "ms_per_step": dt_n / args.steps * 1e3},
+        "ms_per_pair_per_gpu": dt_g / args.steps * 1e3 / max(1, -(-args.batch // world)),
+    }
 
 
 def main():
@@ -70,14 +269,33 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    # the CPU leg runs first, before this process touches the GPU (its all-cores part starts worker processes)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.batch:
+        cpu = cpu_baseline(args.niter, all_cores=not args.cpu_one_core_only)
     dist = torch = None
     multi = world > 1 or args.force_dist
     if multi:
         import torch
         import torch.distributed as dist
+        if args.force_dist and "RANK" not in os.environ:        # one rank started by hand: be its own rendezvous
+            for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29511")):
+                os.environ.setdefault(k, v)
         if args.backend == "nccl":
             torch.cuda.set_device(0 if args.same_device else local)
         dist.init_process_group(args.backend)
+
+    if args.batch:
+        if not multi:
+            import torch
+        result = run_batch_config(args, rank, world, local, dist, torch)
+        if rank == 0:
+            result["cpu_baseline"] = None
+            print(json.dumps(result))
+        if multi:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     import _ofri
     from piv_synth import synth_piv
@@ -197,32 +415,9 @@ def main():
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = world * pairs_per_step * H * W * args.steps / dt / 1e6
-        # dominant kernel: the Jacobi sweep launches of the full-resolution level.  A Horn-Schunck call may use
-        # two kernels there (row-streaming pipeline for the multiples of 12 sweeps, tile kernel for the rest);
-        # the one with the larger share of the time is reported.
-        full = [r for r in recs if r[3] == H and r[4] == W]
-        groups = {}
-        for r in full:
-            # one sweep per launch; tile kernel: at most 8 per launch; row-streaming pipeline: 12 or 16
-            # (a last pipeline launch of 13 to 16 sweeps is another kernel instantiation and is timed on its own)
-            name = "k_hs_sweep" if r[2] == r[1] else ("k_hs_stream_deep" if r[2] > 12 * r[1] else
-                                                      ("k_hs_stream" if r[2] > 8 * r[1] else "k_hs_fused"))
-            groups.setdefault(name, []).append(r)
-        kname, grp = max(groups.items(), key=lambda kv: sum(r[0] for r in kv[1])) if groups else ("none", [])
-        hs_ms_all = sum(r[0] for r in full)
-        ms = sum(r[0] for r in grp)
-        launches = sum(r[1] for r in grp)
-        sweeps = sum(r[2] for r in grp)
-        per_launch_ms = ms / max(launches, 1)
-        sweeps_per_launch = sweeps / max(launches, 1)
-        alg_bytes = HS_BYTES_PER_PX_SWEEP * H * W * sweeps_per_launch
-        achieved = alg_bytes / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
-        traffic = None
-        try:        # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
-            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                traffic = json.load(f).get("%s@%dx%d" % (kname, H, W))
-        except (OSError, ValueError):
-            pass
+        roof = roofline_block(recs, H, W, args.steps, ms_per_step) if not args.graph else None
+        if roof is not None and world == 1 and args.fuse == 0:
+            roof["one_sweep_kernel"] = one_sweep_roofline(ctx, H, W)
         result = {
             "metric": "Mpix/s per PIV frame pair (HS 100-iter @4096^2)",
             "value": value, "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -231,14 +426,8 @@ def main():
             "config": {"workload": "HS Fs3.4, 2-level pyramid, %dx%d synthetic Poiseuille pair, alphas [21,45], "
                                    "%d sweeps/level%s" % (H, W, args.niter, " + Liu-Shen h=5 Fs_opt 0.48 on every level" if args.liushen else ""),
                        "pairs_per_step_per_gpu": pairs_per_step, "flow_gather": gather_note, "captured_graph": bool(args.graph),
-                       "hs_sweeps_per_launch": sweeps_per_launch},
-            "roofline": {"bound": "hbm", "kernel": "%s@%dx%d" % (kname, H, W), "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "launch_ms": per_launch_ms, "launches_timed": launches,
-                         "sweeps_per_launch": sweeps_per_launch,
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "kernel_share_of_step": (ms / args.steps) / ms_per_step if ms_per_step > 0 else None,
-                         "hs_level2_share_of_step": (hs_ms_all / args.steps) / ms_per_step if ms_per_step > 0 else None},
+                       "hs_sweeps_per_launch": roof["sweeps_per_launch"] if roof else None},
+            "roofline": roof,
         }
     if args.with_transfer and rank == 0 and world == 1:
         t = time.perf_counter()
@@ -271,11 +460,8 @@ def main():
             pass
         result["with_transfer_streamed_graph_mpix_s"] = H * W * n_str / (time.perf_counter() - t) / 1e6
         sp.close()
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(args.niter)
-    elif rank == 0:
-        result["cpu_baseline"] = None
     if rank == 0:
+        result["cpu_baseline"] = cpu
         print(json.dumps(result))
     if multi:
         dist.barrier()

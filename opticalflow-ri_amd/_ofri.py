@@ -245,6 +245,13 @@ class Context(object):
             lib().ofri_ctx_destroy(self._h)
             self._h = _vp()
 
+    def __del__(self):
+        # every DeviceArray and Graph holds a reference to its context, so nothing of this context is alive any more
+        try:
+            self.close()
+        except Exception:
+            pass
+
     # ---- arrays
     def empty(self, shape, dtype=np.float32):
         return DeviceArray(self, shape, dtype)

@@ -61,3 +61,218 @@ def max_over_ranks(seconds, device=None, group=None):
     t = torch.tensor([float(seconds)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return float(t.item())
+
+
+# ------------------------------------------------------------------------------------------ batch runner
+class _Job(object):
+    """torch.distributed state of one run_batch call: world, rank and where tensors live."""
+
+    def __init__(self, group, device):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.group = torch, dist, group
+        self.on = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if self.on else 1
+        self.rank = dist.get_rank(group) if self.on else 0
+        self.device = device                       # torch device of the flow tensors ('cpu' for host flows)
+
+
+def _one_hip_runtime():
+    """torch wheels bundle their own HIP runtime under the same soname as the system's.  Whichever is loaded first
+    serves both torch and libofri_hip.so - unless libofri_hip.so came first: torch asks for its copy by another file
+    name, a second runtime is mapped and finds no GPU.  So: import torch before the first _ofri call."""
+    paths = set()
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                if "libamdhip64" in line:
+                    paths.add(line.split()[-1])
+    except OSError:
+        return
+    if len(paths) > 1:
+        raise RuntimeError("two HIP runtimes are mapped in this process (%s): import torch before the first use of "
+                           "libofri_hip.so (any _ofri call), so that both share one runtime" % ", ".join(sorted(paths)))
+
+
+def torch_context(device=0):
+    """An _ofri.Context whose stream is a torch stream made current: the library's kernels, torch's copies and the
+    RCCL collectives torch enqueues are then ordered against each other.  Returns (ctx, torch_stream)."""
+    import torch
+    import _ofri
+    _one_hip_runtime()
+    torch.cuda.set_device(device)
+    stream = torch.cuda.Stream(device=device)
+    torch.cuda.set_stream(stream)
+    return _ofri.Context(device, stream.cuda_stream), stream
+
+
+def hs_liushen_flow(ctx, shape, niter=100, alphas=(21, 45), h=5, FILTER=3.4, FILTER_OPT=0.48, levels=2, graph=True,
+                    liushen=True):
+    """flow_fn(im0, im1) -> (U, V) DeviceArrays for the batch configuration: the call of
+    examples/LiuSE_PyHSchunck_Fs3_4_PyrLvls2.py:133-139 (Horn-Schunck per level, refined by Liu-Shen on the level's
+    images filtered with FILTER_OPT), replayed from a captured graph when ``graph``.  The arrays returned are the
+    plan's own and are overwritten by the next call."""
+    from HornSchunck import HSOpticalFlowAlgoAdapter
+    from PhysicsBasedOpticalFlowLiuShen import LiuShenOpticalFlowAlgoAdapter
+    from GenericPyramidalOpticalFlow import pyramidal_flow_device
+    opt = {"FILTER_OPT": FILTER_OPT, "optionalOFlowAlgoAdapter": LiuShenOpticalFlowAlgoAdapter(h)} if liushen else {}
+    make = lambda: HSOpticalFlowAlgoAdapter(list(alphas), niter)
+    if graph:
+        from piv_plan import FlowPlan
+        plan = FlowPlan(shape, FILTER, make, pyramidalLevels=levels, ctx=ctx, **opt)
+
+        def flow(im0, im1):
+            plan.load(im0, im1)
+            return plan.run()
+        flow.close = plan.close
+        return flow
+
+    def flow(im0, im1):
+        return pyramidal_flow_device(im0, im1, FILTER, make(), levels, 1, opt.get("FILTER_OPT"),
+                                     opt.get("optionalOFlowAlgoAdapter"))
+    flow.close = lambda: None
+    return flow
+
+
+def _device_frames(ctx, pair):
+    """A pair as float32 DeviceArrays: host arrays are uploaded (8/16-bit frames raw, widened on the GPU), resident
+    uint8/uint16 DeviceArrays are widened, float32 DeviceArrays pass through."""
+    import numpy as np
+    import _ofri
+    out = []
+    for f in pair:
+        if isinstance(f, _ofri.DeviceArray):
+            if f.dtype == np.float32:
+                out.append(f)
+                continue
+            d = ctx.empty(f.shape)
+            widen = _ofri.lib().ofri_u8_to_f32 if f.dtype == np.uint8 else _ofri.lib().ofri_u16_to_f32
+            _ofri.check(widen(ctx.handle, f.ptr, d.ptr, f.size))
+            out.append(d)
+        else:
+            out.append(ctx.upload(f))
+    return out[0], out[1]
+
+
+def run_batch(n_pairs, pair_fn, flow_fn, ctx=None, group=None, dst=0, chunk=8, gather=True, stats=None, shape=None):
+    """Flow fields of a batch of independent frame pairs over the ranks of ``group``.
+
+    Rank r works on its contiguous block ``partition(n_pairs, world)[r]``: for every pair p of the block,
+    ``pair_fn(p)`` gives the two frames (host arrays, or DeviceArrays already resident on this rank's GPU) and
+    ``flow_fn(im0, im1)`` their flow (U, V) - DeviceArrays on ``ctx`` (float32 frames in; see hs_liushen_flow), or
+    NumPy arrays from any host function (then ``ctx`` is not used and tensors stay on the CPU: the gloo rehearsal).
+    No collective inside the computation.  The only exchange: every ``chunk`` pairs each rank's new fields go to
+    rank ``dst`` in one asynchronous gather (RCCL on GPU tensors) that overlaps the next chunk's computation; two
+    send buffers alternate, and rank ``dst`` receives straight into its result tensor.
+
+    Returns on rank ``dst`` a float32 tensor (n_pairs, 2, H, W) in pair order ([p, 0] = U, [p, 1] = V), None on the
+    other ranks; with ``gather=False`` every rank returns its own block (n_local, 2, H, W).  Without an initialised
+    process group the call is the single-rank case.  ``ctx`` must have been made by torch_context() when tensors
+    live on the GPU, so that copies, kernels and collectives share a stream order.  ``shape``: (H, W) of a field;
+    needed only when a rank may have no pairs (more ranks than pairs), otherwise taken from the first result.
+    ``stats``: optional dict that receives 'elapsed_s' (this rank's time from its first pair to its last gather) and
+    'pairs' (the rank's count)."""
+    import time
+    import numpy as np
+    import torch
+    import _ofri
+    lib = _ofri.lib() if ctx is not None else None
+    job = _Job(group, None)
+    if n_pairs < 0 or not callable(pair_fn) or not callable(flow_fn):
+        raise ValueError("run_batch(n_pairs >= 0, pair_fn(p), flow_fn(im0, im1))")
+    parts = partition(n_pairs, job.world)
+    a, b = parts[job.rank]
+    n_local, longest = b - a, max(q - p for p, q in parts)
+    chunk = max(1, min(int(chunk), max(longest, 1)))
+    n_chunks = (longest + chunk - 1) // chunk
+    do_gather = gather and job.on
+    on_gpu = ctx is not None
+    if do_gather and shape is None and min(q - p for p, q in parts) == 0:
+        raise ValueError("run_batch: %d pairs over %d ranks leaves a rank without pairs; pass shape=(H, W)" % (n_pairs, job.world))
+    t0 = time.perf_counter()
+
+    state = {"send": None, "result": None, "local": None, "shape": None, "comm": None}
+    pending = []            # gathers in flight, oldest first: (work handle, send buffer index)
+
+    def setup(hw):
+        """Buffers, once the field shape is known (every pair of a batch has the same shape)."""
+        job.device = torch.device("cuda", ctx.device) if on_gpu else torch.device("cpu")
+        H, W = int(hw[0]), int(hw[1])
+        state["shape"] = (H, W)
+        if do_gather:
+            state["send"] = [torch.empty((chunk, 2, H, W), dtype=torch.float32, device=job.device) for _ in range(2)]
+            if job.rank == dst:     # rank r's chunk c lands in result[r, c*chunk:(c+1)*chunk]: a contiguous view each
+                state["result"] = torch.empty((job.world, n_chunks * chunk, 2, H, W), dtype=torch.float32, device=job.device)
+            if on_gpu:
+                state["comm"] = torch.cuda.Stream(device=job.device)
+        else:
+            state["local"] = torch.empty((n_local, 2, H, W), dtype=torch.float32, device=job.device)
+
+    def store(dst_t, U, V):
+        """Copy one flow field into dst_t (2, H, W) in stream order."""
+        if on_gpu and isinstance(U, _ofri.DeviceArray):
+            _ofri.check(lib.ofri_copy(ctx.handle, dst_t[0].data_ptr(), U.ptr, U.nbytes))
+            _ofri.check(lib.ofri_copy(ctx.handle, dst_t[1].data_ptr(), V.ptr, V.nbytes))
+        else:
+            dst_t[0].copy_(torch.from_numpy(np.ascontiguousarray(U, dtype=np.float32)))
+            dst_t[1].copy_(torch.from_numpy(np.ascontiguousarray(V, dtype=np.float32)))
+
+    def post(c):
+        """Start the gather of chunk c (every rank calls this for every c, whether or not it has pairs in it)."""
+        buf = state["send"][c & 1]
+        recv = [state["result"][r, c * chunk:(c + 1) * chunk] for r in range(job.world)] if job.rank == dst else None
+        comm = state["comm"]
+        if comm is not None:
+            comm.wait_stream(torch.cuda.current_stream())        # the chunk's fields are complete
+            with torch.cuda.stream(comm):
+                w = job.dist.gather(buf, recv, dst=dst, group=job.group, async_op=True)
+        else:
+            w = job.dist.gather(buf, recv, dst=dst, group=job.group, async_op=True)
+        pending.append(w)
+
+    def reuse(c):
+        """Before chunk c's send buffer is written again, the gather that last read it (chunk c - 2) must be over."""
+        while len(pending) >= 2:
+            pending.pop(0).wait()
+
+    if shape is not None:
+        setup(shape)
+    k = 0                   # pairs of this rank done so far
+    for c in range(n_chunks):
+        lo, hi = a + c * chunk, min(a + (c + 1) * chunk, b)
+        if do_gather and state["send"] is not None:
+            reuse(c)
+        for p in range(lo, hi):
+            pair = pair_fn(p)
+            if ctx is not None:
+                pair = _device_frames(ctx, pair)
+            U, V = flow_fn(pair[0], pair[1])
+            if state["shape"] is None:
+                setup(np.shape(U) if not isinstance(U, _ofri.DeviceArray) else U.shape)
+            if do_gather:
+                store(state["send"][c & 1][p - lo], U, V)
+            else:
+                store(state["local"][k], U, V)
+            k += 1
+        if do_gather:
+            post(c)
+    while pending:
+        pending.pop(0).wait()
+    if on_gpu:
+        if state["comm"] is not None:
+            torch.cuda.current_stream().wait_stream(state["comm"])
+        ctx.sync()
+    if stats is not None:
+        stats["elapsed_s"] = time.perf_counter() - t0
+        stats["pairs"] = n_local
+    if not do_gather:
+        if state["local"] is None:
+            return torch.empty((0, 2, 0, 0), dtype=torch.float32)
+        return state["local"]
+    if job.rank != dst:
+        return None
+    res = state["result"]
+    H, W = state["shape"]
+    if all(q - p == n_chunks * chunk for p, q in parts):
+        return res.view(n_pairs, 2, H, W)            # equal blocks that fill their chunks: already in pair order
+    return torch.cat([res[r, :q - p] for r, (p, q) in enumerate(parts)], 0)

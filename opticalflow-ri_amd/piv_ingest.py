@@ -163,7 +163,22 @@ class PairFeeder(object):
         finally:
             # a consumer that stops early leaves an upload under way: let it finish before the buffers can go
             self._worker.shutdown(wait=True)
-            self.copy_ctx.sync()
+            self.close()
+
+    def close(self):
+        """Release the copy stream, its events and its staging arrays.  The widen kernels on the compute stream read
+        the raw frames, so that stream is drained first; the raw frames' blocks then leave with the copy context."""
+        if self.copy_ctx is None:
+            return
+        lib = _ofri.lib()
+        self.ctx.sync()
+        self.copy_ctx.sync()
+        for ev in self._events.values():
+            lib.ofri_event_destroy(ev)
+        self._events.clear()
+        self._stage.clear()              # pinned blocks go back to the process-wide pool, raw frames to the copy context
+        self.copy_ctx.close()
+        self.copy_ctx = None
 
 
 class FlowDrain(object):
@@ -175,6 +190,7 @@ class FlowDrain(object):
     def __init__(self, ctx):
         self.ctx = ctx
         self.copy_ctx = _ofri.Context(ctx.device)
+        self._open = {}                  # tickets posted and not fetched: id -> ticket
 
     def post(self, *arrays):
         lib = _ofri.lib()
@@ -188,11 +204,14 @@ class FlowDrain(object):
         ev = self.copy_ctx.event()
         self.copy_ctx.record(ev)
         # the device arrays stay referenced until fetch: their memory must not go back to the pool under the copy
-        return (arrays, leases, ev)
+        t = (arrays, leases, ev)
+        self._open[id(t)] = t
+        return t
 
     def fetch(self, ticket):
         arrays, leases, ev = ticket
         lib = _ofri.lib()
+        self._open.pop(id(ticket), None)
         _ofri.check(lib.ofri_event_sync(ev))
         lib.ofri_event_destroy(ev)
         out = []
@@ -203,6 +222,19 @@ class FlowDrain(object):
                 out.append(np.asarray(lease).view(a.dtype).reshape(a.shape))
         return tuple(out)
 
+    def close(self):
+        """Wait for copies still under way (a consumer that stopped early leaves a ticket unfetched: its pinned blocks
+        and device arrays must not be handed out again under the copy), then release the copy stream."""
+        if self.copy_ctx is None:
+            return
+        lib = _ofri.lib()
+        self.copy_ctx.sync()
+        for _, _, ev in self._open.values():
+            lib.ofri_event_destroy(ev)
+        self._open.clear()
+        self.copy_ctx.close()
+        self.copy_ctx = None
+
 
 def stream_flows(ctx, pairs, flow_fn, range_rule=False):
     """Flow fields of a sequence of host frame pairs with all three legs overlapped: while ``flow_fn(im0, im1)``
@@ -210,10 +242,14 @@ def stream_flows(ctx, pairs, flow_fn, range_rule=False):
     i-1 is copied back.  Yields the host results in pair order."""
     drain = FlowDrain(ctx)
     prev = None
-    for im0, im1 in PairFeeder(ctx, pairs, range_rule):
-        t = drain.post(*flow_fn(im0, im1))
+    try:
+        for im0, im1 in PairFeeder(ctx, pairs, range_rule):
+            t = drain.post(*flow_fn(im0, im1))
+            if prev is not None:
+                yield drain.fetch(prev)
+            prev = t
         if prev is not None:
-            yield drain.fetch(prev)
-        prev = t
-    if prev is not None:
-        yield drain.fetch(prev)
+            t, prev = prev, None
+            yield drain.fetch(t)
+    finally:
+        drain.close()
