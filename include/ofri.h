@@ -182,6 +182,16 @@ int ofri_hs_level(ofri_ctx *ctx, const float *im1, const float *im2, float *U_fl
 int ofri_ls_compute(ofri_ctx *ctx, const float *im1, const float *im2, const float *u_in,
                     const float *v_in, float *u_out, float *v_out, float h, int maxit, double tol,
                     int rows, int cols, double *err_host, int *iters_host);
+/* Arithmetic and launch shape of the Liu-Shen sweeps (:141-156), like ofri_hs_set_fuse for Horn-Schunck:
+ *   mode = 0   automatic: float32 arithmetic with fused multiply-adds in one pinned order; the row-streaming pipeline
+ *              (6 sweeps per launch) on fields of 512 x 512 pixels and more whose width is a multiple of 4, one sweep
+ *              per launch otherwise;
+ *   mode = 1   the same arithmetic, one launch per sweep;   mode = 6 / 8   the pipeline at that depth, any field size;
+ *   mode = -1  exact mode: scipy's float64 stencil sums and NumPy's separately rounded float32 products, one launch
+ *              per sweep, the reference's bits.
+ * All settings but -1 give the same flow bits as each other (about 1e-7 relative from the exact mode per call); the
+ * stopping rule is the reference's in every mode (total_error as float32, at most maxit sweeps). */
+int ofri_ls_set_mode(ofri_ctx *ctx, int mode);
 
 /* ---- Farneback polynomial expansion --------------------------------------------------------------- */
 /* 5-plane arrays (R0, R1, M) hold their planes stacked vertically: plane k is rows k*rows..(k+1)*rows-1

@@ -501,16 +501,16 @@ def test_liushen_stopping_rule_and_tiny_shapes(ctx):
     np.testing.assert_array_equal(ud.numpy(), ur)
 
 
-@pytest.mark.parametrize("big", [False, True])
-def test_liushen_stops_at_every_iteration_count(ctx, pair, big):
-    """The stopping check of a sweep runs inside the next sweep's launch, which has then already started: whatever the
-    count at which the rule is met (odd, even, the last allowed one), the result must be that sweep's, bit for bit,
-    and the count the reference's loop would report."""
+@pytest.mark.parametrize("big,mode", [(False, 0), (True, 0), (False, -1), (False, 1), (False, 6), (True, 6), (False, 8)])
+def test_liushen_stops_at_every_iteration_count(ctx, pair, big, mode):
+    """The stopping check of a block of sweeps runs inside the next launch, which has then already started: whatever the
+    count at which the rule is met (odd, even, inside a launch of several sweeps, the last allowed one), the result
+    must be that sweep's, bit for bit, and the count the reference's loop would report."""
     import ctypes as C
     import _ofri
     lib = _ofri.lib()
     if big:
-        I0, I1 = np.tile(pair[0], (2, 2))[:1000, :1030].copy(), np.tile(pair[1], (2, 2))[:1000, :1030].copy()
+        I0, I1 = np.tile(pair[0], (2, 2))[:1000, :1032].copy(), np.tile(pair[1], (2, 2))[:1000, :1032].copy()
     else:
         I0, I1 = pair[0][100:230, 60:260].copy(), pair[1][100:230, 60:260].copy()
     rows, cols = I0.shape
@@ -523,19 +523,71 @@ def test_liushen_stops_at_every_iteration_count(ctx, pair, big):
                                         C.byref(err), C.byref(it)))
         return u.numpy(), v.numpy(), err.value, it.value
 
-    fixed = {k: run(k, 0.0) for k in range(0, 10)}            # tol = 0: exactly k sweeps
-    assert [fixed[k][3] for k in range(10)] == list(range(10))
-    np.testing.assert_array_equal(fixed[0][0], 0.0)
-    errs = [fixed[k][2] for k in range(1, 10)]
-    assert all(e1 > e2 > 0 for e1, e2 in zip(errs, errs[1:])), errs    # the change per sweep shrinks on this pair
-    for k in range(1, 9):
-        tol = 0.5 * (fixed[k][2] + fixed[k + 1][2])           # err_k > tol > err_(k+1): first met by sweep k+1
-        u, v, e, it = run(60, tol)
-        assert it == k + 1 and e == fixed[k + 1][2]
-        np.testing.assert_array_equal(u, fixed[k + 1][0]); np.testing.assert_array_equal(v, fixed[k + 1][1])
-        u, v, e, it = run(k, tol)                             # the cap comes first
-        assert it == k
-        np.testing.assert_array_equal(u, fixed[k][0])
+    ctx.set_ls_mode(mode)
+    try:
+        fixed = {k: run(k, 0.0) for k in range(0, 16)}            # tol = 0: exactly k sweeps
+        assert [fixed[k][3] for k in range(16)] == list(range(16))
+        np.testing.assert_array_equal(fixed[0][0], 0.0)
+        errs = [fixed[k][2] for k in range(1, 16)]
+        assert all(e1 > e2 > 0 for e1, e2 in zip(errs, errs[1:])), errs    # the change per sweep shrinks on this pair
+        for k in range(1, 15):
+            tol = 0.5 * (fixed[k][2] + fixed[k + 1][2])           # err_k > tol > err_(k+1): first met by sweep k+1
+            u, v, e, it = run(60, tol)
+            assert it == k + 1 and e == fixed[k + 1][2]
+            np.testing.assert_array_equal(u, fixed[k + 1][0]); np.testing.assert_array_equal(v, fixed[k + 1][1])
+            u, v, e, it = run(k, tol)                             # the cap comes first
+            assert it == k
+            np.testing.assert_array_equal(u, fixed[k][0])
+    finally:
+        ctx.set_ls_mode(0)
+
+
+@pytest.mark.parametrize("shape", [(130, 200), (256, 256), (1000, 1032), (64, 8), (3, 128), (1, 16), (257, 124), (40, 1024)])
+def test_liushen_launch_shapes_agree_bitwise(ctx, shape):
+    """One sweep per launch, the 6-deep and the 8-deep pipeline run the same float32 arithmetic: same bits and counts for
+    any field shape (image edges inside a strip, strips wider than the image, fewer rows than the pipeline is deep) and
+    any number of sweeps; the exact mode (the reference's bits) lies within 1e-5 of them."""
+    from oracle import gauss, liushen
+    from PhysicsBasedOpticalFlowLiuShen import liushen_device
+    from piv_synth import synth_piv
+    rng = np.random.default_rng(shape[0])
+    H, W = shape
+    f0, f1 = synth_piv(max(H, 8), max(W, 8), seed=H + W)
+    I0 = gauss.filter_px(f0.astype(np.float32), 0.48, 5)[:H, :W].copy(); I1 = gauss.filter_px(f1.astype(np.float32), 0.48, 5)[:H, :W].copy()
+    I0[0, 0] += 1.0                                               # never an all-zero crop
+    U0 = (0.3 * rng.standard_normal(shape)).astype(np.float32); V0 = (0.3 * rng.standard_normal(shape)).astype(np.float32)
+    d = [ctx.upload(x) for x in (I0, I1, U0, V0)]
+    try:
+        for maxit in (1, 5, 6, 7, 13, 60):
+            res = {}
+            for mode in (1, 6, 8, -1):
+                ctx.set_ls_mode(mode)
+                u, v, e, it = liushen_device(d[0], d[1], 5.0, d[2], d[3], True)[:4] if maxit == 60 else _ls_run(ctx, d, maxit)
+                res[mode] = (u.numpy(), v.numpy(), e, it)
+            for mode in (6, 8):
+                np.testing.assert_array_equal(res[mode][0], res[1][0], err_msg="u, depth %d, %d sweeps" % (mode, maxit))
+                np.testing.assert_array_equal(res[mode][1], res[1][1], err_msg="v, depth %d, %d sweeps" % (mode, maxit))
+                assert res[mode][3] == res[1][3]
+                assert res[mode][2] == pytest.approx(res[1][2], rel=1e-5)
+            assert res[-1][3] == res[1][3]
+            assert flow_rel(res[1][0], res[1][1], res[-1][0], res[-1][1]) < 1e-5, maxit
+        ur, vr, er, itr = liushen.liushen(I0, I1, 5.0, U0.copy(), V0.copy(), return_iters=True)
+        assert itr == res[-1][3]
+        np.testing.assert_array_equal(res[-1][0], ur)             # exact mode: the oracle's bits
+        np.testing.assert_array_equal(res[-1][1], vr)
+    finally:
+        ctx.set_ls_mode(0)
+
+
+def _ls_run(ctx, d, maxit, tol=1e-8):
+    import ctypes as C
+    import _ofri
+    rows, cols = d[0].shape
+    u, v = ctx.empty((rows, cols)), ctx.empty((rows, cols))
+    err, it = C.c_double(0.0), C.c_int(0)
+    _ofri.check(_ofri.lib().ofri_ls_compute(ctx.handle, d[0].ptr, d[1].ptr, d[2].ptr, d[3].ptr, u.ptr, v.ptr, 5.0, maxit, tol,
+                                            rows, cols, C.byref(err), C.byref(it)))
+    return u, v, err.value, it.value
 
 
 def test_driver_hs_plus_liushen_and_ls_main(ctx, pair):
