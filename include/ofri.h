@@ -194,6 +194,12 @@ int ofri_ls_compute(ofri_ctx *ctx, const float *im1, const float *im2, const flo
 int ofri_ls_set_mode(ofri_ctx *ctx, int mode);
 
 /* ---- Farneback polynomial expansion --------------------------------------------------------------- */
+/* Arithmetic of every ofri_fb_* kernel on this context:
+ *   mode = 0   fast (default): float32 in the kernel text's order with a * b + c contracted into fused multiply-adds, as an
+ *              OpenCL compiler may do with the reference's source (optical_flow_farneback.cl:222-227, 244-247);
+ *   mode = -1  exact: products and sums rounded separately, the bits of the CPU restatement of the OpenCL text.
+ * The two differ by about 1e-7 relative per kernel. */
+int ofri_fb_set_mode(ofri_ctx *ctx, int mode);
 /* 5-plane arrays (R0, R1, M) hold their planes stacked vertically: plane k is rows k*rows..(k+1)*rows-1
  * of a (5*rows, cols) float32 array, as in the reference (src/Farneback_PyCL.py:542-545).
  * polynomialExpansion (src/optical_flow_farneback.cl:72-133; host src/Farneback_PyCL.py:311-356):

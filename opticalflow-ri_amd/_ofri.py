@@ -68,6 +68,7 @@ _PROTOS = {
     "ofri_hs_level": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _i, _i], _i),
     "ofri_ls_compute": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _d, _i, _i, C.POINTER(_d), C.POINTER(_i)], _i),
     "ofri_ls_set_mode": ([_vp, _i], _i),
+    "ofri_fb_set_mode": ([_vp, _i], _i),
     "ofri_fb_polyexp": ([_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp], _i),
     "ofri_fb_blur_polyexp": ([_vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp], _i),
     "ofri_fb_blur": ([_vp, _vp, _vp, _i, _i, _vp, _i], _i),
@@ -226,6 +227,9 @@ class Context(object):
 
     def set_hs_fuse(self, t):
         check(lib().ofri_hs_set_fuse(self._h, int(t)))
+
+    def set_fb_mode(self, mode):
+        check(lib().ofri_fb_set_mode(self._h, int(mode)))
 
     def set_ls_mode(self, mode):
         check(lib().ofri_ls_set_mode(self._h, int(mode)))

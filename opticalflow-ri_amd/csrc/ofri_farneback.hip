@@ -1,9 +1,12 @@
 // Farneback polynomial-expansion optical flow kernels.
 // Reference behaviour: src/optical_flow_farneback.cl:72-429 (OpenCV-derived OpenCL kernels) and their
-// host wrappers src/Farneback_PyCL.py:211-457.  Arithmetic follows the kernel text operation by
-// operation in float32 with separately rounded products and sums (no FMA contraction in this file).
+// host wrappers src/Farneback_PyCL.py:211-457.  The kernels (ofri_farneback_kernels.h) follow the kernel text operation
+// by operation in float32 and are compiled twice: in namespace fb_exact with separately rounded products and sums (no
+// FMA contraction: the bits of the CPU restatement of the OpenCL text), in namespace fb_fast with a * b + c contracted
+// into fused multiply-adds, which an OpenCL compiler is free to do with the reference's own source as well
+// (optical_flow_farneback.cl:222-227, 244-247) and which takes a third of the operations out of the window filter.
+// ofri_fb_set_mode picks one per context (fast by default).
 #include "ofri_internal.h"
-#pragma clang fp contract(off)
 
 #define FB_MAX_KSH 100                 // MAX_KSIZE_HALF of the reference
 struct FbTaps { float k[FB_MAX_KSH + 1]; };
@@ -15,559 +18,62 @@ __device__ __forceinline__ int fb_high(int y, int last) { return abs(last - abs(
 // in-range indices map to themselves under both helpers; only out-of-range ones pay for the modulo
 __device__ __forceinline__ int fb_idx(int t, int last) { return (unsigned)t <= (unsigned)last ? t : fb_low(fb_high(t, last), last); }
 
-// ---- polynomial expansion (.cl:72-133) -----------------------------------------------------------
-#define PE_TX 64
-#define PE_TY 8
-template <int N>
-__global__ void __launch_bounds__(256)
-k_fb_polyexp(const float *__restrict__ src, float *__restrict__ dst, int H, int W, FbPoly c) {
-    __shared__ float r0[PE_TY][PE_TX + 2 * N], r1[PE_TY][PE_TX + 2 * N], r2[PE_TY][PE_TX + 2 * N];
-    const int bx = blockIdx.x * PE_TX, by = blockIdx.y * PE_TY, tid = threadIdx.y * 64 + threadIdx.x;
-    // vertical pass; rows clamped (:98-99), columns clamped (:89)
-    for (int i = tid; i < PE_TY * (PE_TX + 2 * N); i += 256) {
-        int ly = i / (PE_TX + 2 * N), lx = i - ly * (PE_TX + 2 * N);
-        int y = by + ly, x = clampi(bx + lx - N, 0, W - 1);
-        float a = 0.f, b = 0.f, d = 0.f;
-        if (y < H) {
-            a = src[(size_t)y * W + x] * c.g[0];
-#pragma unroll
-            for (int k = 1; k <= N; ++k) {
-                float t0 = src[(size_t)max(y - k, 0) * W + x];
-                float t1 = src[(size_t)min(y + k, H - 1) * W + x];
-                a += c.g[k] * (t0 + t1);
-                b += c.xg[k] * (t1 - t0);
-                d += c.xxg[k] * (t0 + t1);
-            }
-        }
-        r0[ly][lx] = a; r1[ly][lx] = b; r2[ly][lx] = d;
-    }
-    __syncthreads();
-    for (int i = tid; i < PE_TY * PE_TX; i += 256) {
-        int ly = i / PE_TX, lx = i - ly * PE_TX;
-        int y = by + ly, x = bx + lx;
-        if (y >= H || x >= W) continue;
-        const float *p0 = &r0[ly][lx + N], *p1 = &r1[ly][lx + N], *p2 = &r2[ly][lx + N];
-        float b1 = c.g[0] * p0[0], b3 = c.g[0] * p1[0], b5 = c.g[0] * p2[0], b2 = 0.f, b4 = 0.f, b6 = 0.f;
-#pragma unroll
-        for (int k = 1; k <= N; ++k) {
-            b1 += (p0[k] + p0[-k]) * c.g[k];
-            b4 += (p0[k] + p0[-k]) * c.xxg[k];
-            b2 += (p0[k] - p0[-k]) * c.xg[k];
-            b3 += (p1[k] + p1[-k]) * c.g[k];
-            b6 += (p1[k] - p1[-k]) * c.xg[k];
-            b5 += (p2[k] + p2[-k]) * c.g[k];
-        }
-        size_t o = (size_t)y * W + x, P = (size_t)H * W;
-        dst[o] = b3 * c.ig[0];
-        dst[P + o] = b2 * c.ig[0];
-        dst[2 * P + o] = b1 * c.ig[1] + b5 * c.ig[2];
-        dst[3 * P + o] = b1 * c.ig[1] + b4 * c.ig[2];
-        dst[4 * P + o] = b6 * c.ig[3];
-    }
+
+// ---- updateMatrices border attenuation (.cl:254) ------------------------------------------------------
+__constant__ float c_fb_border[6] = {0.14f, 0.14f, 0.4472f, 0.4472f, 0.4472f, 1.f};
+
+namespace fb_exact {
+#pragma clang fp contract(off)
+#include "ofri_farneback_kernels.h"
+}  // namespace fb_exact
+namespace fb_fast {
+#pragma clang fp contract(fast)
+#include "ofri_farneback_kernels.h"
+}  // namespace fb_fast
+#pragma clang fp contract(off)
+
+extern "C" int ofri_fb_set_mode(ofri_ctx *ctx, int mode) {
+    OFRI_REQUIRE(ctx, "null context");
+    OFRI_REQUIRE(mode == 0 || mode == -1, "mode: 0 fast (fused multiply-adds), -1 exact (separately rounded operations)");
+    ctx->fb_mode = mode;
+    return OFRI_OK;
 }
+
+#define FB_DISPATCH(ctx, call) ((ctx) && (ctx)->fb_mode == -1 ? fb_exact::call : fb_fast::call)
 
 extern "C" int ofri_fb_polyexp(ofri_ctx *ctx, const float *src, float *dst5, int rows, int cols, int polyN,
                                const float *g_host, const float *xg_host, const float *xxg_host, const float *ig_host) {
-    OFRI_TRY(ofri_check_ctx(ctx));
-    OFRI_REQUIRE(src && dst5 && g_host && xg_host && xxg_host && ig_host, "null pointer");
-    OFRI_REQUIRE(rows > 0 && cols > 0, "bad shape");
-    OFRI_REQUIRE(polyN == 5 || polyN == 7, "polyN must be 5 or 7");       // Farneback_PyCL.py:463
-    FbPoly c;
-    memset(&c, 0, sizeof(c));
-    memcpy(c.g, g_host, (polyN + 1) * sizeof(float));
-    memcpy(c.xg, xg_host, (polyN + 1) * sizeof(float));
-    memcpy(c.xxg, xxg_host, (polyN + 1) * sizeof(float));
-    memcpy(c.ig, ig_host, 4 * sizeof(float));
-    dim3 b(64, 4), g(ceil_div(cols, PE_TX), ceil_div(rows, PE_TY));
-    if (polyN == 5) k_fb_polyexp<5><<<g, b, 0, ctx->stream>>>(src, dst5, rows, cols, c);
-    else k_fb_polyexp<7><<<g, b, 0, ctx->stream>>>(src, dst5, rows, cols, c);
-    OFRI_LAUNCH_CHECK();
-    return OFRI_OK;
+    return FB_DISPATCH(ctx, fbk_polyexp(ctx, src, dst5, rows, cols, polyN, g_host, xg_host, xxg_host, ig_host));
 }
-
-// ---- pre-blur + polynomial expansion in one launch --------------------------------------------------
-// The reference blurs every frame with a 3-tap kernel before expanding it (Farneback_PyCL.py:563-585; with the
-// default single internal level the resize between the two is an identity).  Here a workgroup stages the source
-// tile of its 64 x 16 outputs (polyN + 1 more on every side, reflect-101 like gaussianBlur), blurs it in LDS
-// (vertical pass, then horizontal, the order and arithmetic of k_fb_window) and expands the blurred tile with the
-// arithmetic of k_fb_polyexp, whose rows and columns are clamped to the image: same bits as the two kernels.
-#define BP_TX 64
-#define BP_TY 16
-template <int N>
-__global__ void __launch_bounds__(256)
-k_fb_blur3_polyexp(const float *__restrict__ src, float *__restrict__ dst, int H, int W, float k0, float k1, FbPoly c) {
-    constexpr int SW = BP_TX + 2 * N + 2, SH = BP_TY + 2 * N + 2;     // source tile
-    constexpr int BW = BP_TX + 2 * N, BH = BP_TY + 2 * N;             // blurred tile: image rows by-N .., columns bx-N ..
-    __shared__ float pool[SH * SW + BH * SW];                         // source tile + vertical pass; later r0, r1, r2
-    __shared__ float B[BH][BW];
-    static_assert(3 * BP_TY * BW <= SH * SW + BH * SW, "the three partial-sum planes fit where the blur's tiles were");
-    float (*S)[SW] = reinterpret_cast<float (*)[SW]>(pool);
-    float (*V)[SW] = reinterpret_cast<float (*)[SW]>(pool + SH * SW);
-    float (*r0)[BW] = reinterpret_cast<float (*)[BW]>(pool);
-    float (*r1)[BW] = reinterpret_cast<float (*)[BW]>(pool + BP_TY * BW);
-    float (*r2)[BW] = reinterpret_cast<float (*)[BW]>(pool + 2 * BP_TY * BW);
-    const int bx = blockIdx.x * BP_TX, by = blockIdx.y * BP_TY, tid = threadIdx.x;
-    for (int i = tid; i < SH * SW; i += 256) {
-        const int ly = i / SW, lx = i - ly * SW;
-        const int y = fb_idx(by - N - 1 + ly, H - 1), x = fb_idx(bx - N - 1 + lx, W - 1);
-        S[ly][lx] = src[(size_t)y * W + x];
-    }
-    __syncthreads();
-    for (int i = tid; i < BH * SW; i += 256) {
-        const int ly = i / SW, lx = i - ly * SW;
-        float acc = S[ly + 1][lx] * k0;
-        acc += (S[ly][lx] + S[ly + 2][lx]) * k1;
-        V[ly][lx] = acc;
-    }
-    __syncthreads();
-    for (int i = tid; i < BH * BW; i += 256) {
-        const int ly = i / BW, lx = i - ly * BW;
-        float acc = V[ly][lx + 1] * k0;
-        acc += (V[ly][lx] + V[ly][lx + 2]) * k1;
-        B[ly][lx] = acc;
-    }
-    __syncthreads();
-    // expansion, vertical pass; rows clamped (:98-99), columns clamped (:89).  Entries of B outside the image are never read.
-    for (int i = tid; i < BP_TY * BW; i += 256) {
-        const int ly = i / BW, lx = i - ly * BW;
-        const int y = by + ly, col = clampi(bx + lx - N, 0, W - 1) - (bx - N);
-        float a = 0.f, b = 0.f, d = 0.f;
-        if (y < H) {
-            a = B[ly + N][col] * c.g[0];
-#pragma unroll
-            for (int k = 1; k <= N; ++k) {
-                float t0 = B[max(y - k, 0) - (by - N)][col];
-                float t1 = B[min(y + k, H - 1) - (by - N)][col];
-                a += c.g[k] * (t0 + t1);
-                b += c.xg[k] * (t1 - t0);
-                d += c.xxg[k] * (t0 + t1);
-            }
-        }
-        r0[ly][lx] = a; r1[ly][lx] = b; r2[ly][lx] = d;
-    }
-    __syncthreads();
-    for (int i = tid; i < BP_TY * BP_TX; i += 256) {
-        const int ly = i / BP_TX, lx = i - ly * BP_TX;
-        const int y = by + ly, x = bx + lx;
-        if (y >= H || x >= W) continue;
-        const float *p0 = &r0[ly][lx + N], *p1 = &r1[ly][lx + N], *p2 = &r2[ly][lx + N];
-        float b1 = c.g[0] * p0[0], b3 = c.g[0] * p1[0], b5 = c.g[0] * p2[0], b2 = 0.f, b4 = 0.f, b6 = 0.f;
-#pragma unroll
-        for (int k = 1; k <= N; ++k) {
-            b1 += (p0[k] + p0[-k]) * c.g[k];
-            b4 += (p0[k] + p0[-k]) * c.xxg[k];
-            b2 += (p0[k] - p0[-k]) * c.xg[k];
-            b3 += (p1[k] + p1[-k]) * c.g[k];
-            b6 += (p1[k] - p1[-k]) * c.xg[k];
-            b5 += (p2[k] + p2[-k]) * c.g[k];
-        }
-        size_t o = (size_t)y * W + x, P = (size_t)H * W;
-        dst[o] = b3 * c.ig[0];
-        dst[P + o] = b2 * c.ig[0];
-        dst[2 * P + o] = b1 * c.ig[1] + b5 * c.ig[2];
-        dst[3 * P + o] = b1 * c.ig[1] + b4 * c.ig[2];
-        dst[4 * P + o] = b6 * c.ig[3];
-    }
-}
-
-// ---- updateMatrices (.cl:256-348) -------------------------------------------------------------------
-__constant__ float c_fb_border[6] = {0.14f, 0.14f, 0.4472f, 0.4472f, 0.4472f, 1.f};
-
-// the five matrix entries of pixel (y, x) from its displacement (dx, dy) and the two expansions
-__device__ __forceinline__ void fb_matrices_at(int x, int y, float dx, float dy, const float *__restrict__ R0,
-                                               const float *__restrict__ R1, float *__restrict__ M, int H, int W) {
-    const size_t P = (size_t)H * W, o = (size_t)y * W + x;
-    float fx = x + dx, fy = y + dy;
-    // convert_int(floor(.)): saturate so that absurd displacements stay "outside" instead of wrapping
-    float flx = floorf(fx), fly = floorf(fy);
-    int x1 = (int)fminf(fmaxf(flx, -1e9f), 1e9f), y1 = (int)fminf(fmaxf(fly, -1e9f), 1e9f);
-    fx -= x1;
-    fy -= y1;
-    float r2, r3, r4, r5, r6;
-    if (x1 >= 0 && y1 >= 0 && x1 < W - 1 && y1 < H - 1) {
-        float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
-        size_t q = (size_t)y1 * W + x1;
-        const float *p = R1;
-        r2 = a00 * p[q] + a01 * p[q + 1] + a10 * p[q + W] + a11 * p[q + W + 1]; p += P;
-        r3 = a00 * p[q] + a01 * p[q + 1] + a10 * p[q + W] + a11 * p[q + W + 1]; p += P;
-        r4 = a00 * p[q] + a01 * p[q + 1] + a10 * p[q + W] + a11 * p[q + W + 1]; p += P;
-        r5 = a00 * p[q] + a01 * p[q + 1] + a10 * p[q + W] + a11 * p[q + W + 1]; p += P;
-        r6 = a00 * p[q] + a01 * p[q + 1] + a10 * p[q + W] + a11 * p[q + W + 1];
-        r4 = (R0[2 * P + o] + r4) * 0.5f;
-        r5 = (R0[3 * P + o] + r5) * 0.5f;
-        r6 = (R0[4 * P + o] + r6) * 0.25f;
-    } else {
-        r2 = r3 = 0.f;
-        r4 = R0[2 * P + o];
-        r5 = R0[3 * P + o];
-        r6 = R0[4 * P + o] * 0.5f;
-    }
-    r2 = (R0[o] - r2) * 0.5f;
-    r3 = (R0[P + o] - r3) * 0.5f;
-    r2 += r4 * dy + r6 * dx;
-    r3 += r6 * dy + r5 * dx;
-    float scale = c_fb_border[min(x, 5)] * c_fb_border[min(y, 5)] * c_fb_border[min(W - x - 1, 5)] * c_fb_border[min(H - y - 1, 5)];
-    r2 *= scale; r3 *= scale; r4 *= scale; r5 *= scale; r6 *= scale;
-    M[o] = r4 * r4 + r6 * r6;
-    M[P + o] = (r4 + r5) * r6;
-    M[2 * P + o] = r5 * r5 + r6 * r6;
-    M[3 * P + o] = r4 * r2 + r6 * r3;
-    M[4 * P + o] = r6 * r2 + r5 * r3;
-}
-
-// ---- separable window filter on NP stacked planes (.cl:160-253, 350-406) -------------------------
-// One workgroup: 64 x 16 outputs.  Per plane the (16+2k) x (64+2k) source tile goes to LDS once, the
-// vertical pass writes 16 x (64+2k) partial sums to LDS, the horizontal pass leaves 4 results per
-// thread in registers.  MODE 0: Gaussian taps, reflect-101 border.  MODE 1: box, clamped border.
-// FLOW: instead of storing the NP = 5 filtered planes, solve the 2x2 system per pixel (.cl:408-429).
-#define BL_TX 64
-#define BL_TY 16
-template <int NP, int MODE, bool FLOW>
-__global__ void __launch_bounds__(256)
-k_fb_window(const float *__restrict__ src, float *__restrict__ dst, float *__restrict__ flowx, float *__restrict__ flowy,
-            int H, int W, int ksh, FbTaps taps) {
-    extern __shared__ float lds[];
-    const int TW = BL_TX + 2 * ksh, TH = BL_TY + 2 * ksh;
-    float *tin = lds;                     // TH x TW
-    float *tv = lds + (size_t)TH * TW;    // BL_TY x TW
-    const int bx = blockIdx.x * BL_TX, by = blockIdx.y * BL_TY;
-    const size_t P = (size_t)H * W;
-    float res[NP][4];
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-        const float *sp = src + p * P;
-        for (int ly = threadIdx.y; ly < TH; ly += 4) {
-            int y = by + ly - ksh;
-            y = MODE == 0 ? fb_idx(y, H - 1) : clampi(y, 0, H - 1);
-            for (int lx = threadIdx.x; lx < TW; lx += 64) {
-                int x = bx + lx - ksh;
-                x = MODE == 0 ? fb_idx(x, W - 1) : clampi(x, 0, W - 1);
-                tin[ly * TW + lx] = sp[(size_t)y * W + x];
-            }
-        }
-        __syncthreads();
-        for (int ly = threadIdx.y; ly < BL_TY; ly += 4)
-            for (int lx = threadIdx.x; lx < TW; lx += 64) {
-                const float *c = tin + (size_t)(ly + ksh) * TW + lx;
-                float acc = MODE == 0 ? c[0] * taps.k[0] : c[0];
-                for (int j = 1; j <= ksh; ++j) {
-                    float s = c[-j * TW] + c[j * TW];
-                    acc += MODE == 0 ? s * taps.k[j] : s;
-                }
-                tv[ly * TW + lx] = acc;
-            }
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float *c = tv + (size_t)(threadIdx.y * 4 + r) * TW + threadIdx.x + ksh;
-            float acc = MODE == 0 ? c[0] * taps.k[0] : c[0];
-            for (int i = 1; i <= ksh; ++i) {
-                float s = c[-i] + c[i];
-                acc += MODE == 0 ? s * taps.k[i] : s;
-            }
-            res[p][r] = acc;
-        }
-        // the next plane's load overwrites tin only; tv is rewritten after the barrier that follows that load
-    }
-    const float box_inv = 1.f / ((1 + 2 * ksh) * (1 + 2 * ksh));
-    const int x = bx + threadIdx.x;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        int y = by + threadIdx.y * 4 + r;
-        if (x >= W || y >= H) continue;
-        size_t o = (size_t)y * W + x;
-        float v[NP];
-#pragma unroll
-        for (int p = 0; p < NP; ++p) v[p] = MODE == 0 ? res[p][r] : res[p][r] * box_inv;
-        if (FLOW) {
-            float g11 = v[0], g12 = v[NP > 1 ? 1 : 0], g22 = v[NP > 2 ? 2 : 0], h1 = v[NP > 3 ? 3 : 0], h2 = v[NP > 4 ? 4 : 0];
-            float detInv = 1.f / (g11 * g22 - g12 * g12 + 1e-3f);
-            flowx[o] = (g11 * h2 - g12 * h1) * detInv;
-            flowy[o] = (g22 * h1 - g12 * h2) * detInv;
-        } else {
-#pragma unroll
-            for (int p = 0; p < NP; ++p) dst[p * P + o] = v[p];
-        }
-    }
-}
-
-// Same filter for the reference's default window (ksize_half = 16, windowSize 33), with register
-// windows: a workgroup makes a 64 x 32 tile; the vertical pass gives each thread 4 stacked outputs of one
-// column (36 LDS reads for 4 results instead of 132), three such columns per thread (8 row groups x 96 columns
-// over 256 threads: every wavefront does the same work), the horizontal pass 4 adjacent outputs of one row
-// fetched as nine 16-byte LDS reads, two rows per thread.  Taps are applied in the reference's order (centre,
-// then pairs outward), so results are identical to k_fb_window.
-// UM (with FLOW): the matrices of the next iteration are made from the new displacement on the spot (updateMatrices,
-// a per-pixel step) and stored to Mnext; the displacement itself is stored only where flowx is given.
-#define BW_TY 32
-template <int NP, int MODE, bool FLOW, bool UM = false>
-__global__ void __launch_bounds__(256)
-k_fb_window16(const float *__restrict__ src, float *__restrict__ dst, float *__restrict__ flowx, float *__restrict__ flowy,
-              int H, int W, FbTaps taps, const float *__restrict__ R0 = nullptr, const float *__restrict__ R1 = nullptr,
-              float *__restrict__ Mnext = nullptr) {
-    constexpr int KSH = 16, TW = BL_TX + 2 * KSH, TH = BW_TY + 2 * KSH;      // 96 x 64
-    constexpr int NLD = TH / 8 * 3;                                          // loads per thread and plane
-    constexpr int NR = BW_TY / 16;                                           // output rows per thread
-    __shared__ float tin[TH][TW];
-    __shared__ __attribute__((aligned(16))) float tv[BW_TY][TW];
-    const int bx = blockIdx.x * BL_TX, by = blockIdx.y * BW_TY, tid = threadIdx.x;
-    const size_t P = (size_t)H * W;
-    const int ly = tid >> 4, xg = tid & 15;                                  // horizontal pass: row (and row + 16), group of 4 columns
-    float res[NP][NR][4];
-    // this thread's samples of a plane's 64 x 96 source tile: rows (tid>>5) + 8s, columns (tid&31) + 32q.
-    // All loads of a plane are issued together, and the next plane's are issued before the current
-    // plane is filtered, so their latency hides behind the arithmetic.
-    unsigned roff[TH / 8], coff[3];     // row and column parts of the offsets; the launcher guarantees rows*cols < 2^32
-#pragma unroll
-    for (int sidx = 0; sidx < TH / 8; ++sidx) {
-        int y = by + (tid >> 5) + 8 * sidx - KSH;
-        y = MODE == 0 ? fb_idx(y, H - 1) : clampi(y, 0, H - 1);
-        roff[sidx] = (unsigned)y * (unsigned)W;
-    }
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        int x = bx + (tid & 31) + 32 * q - KSH;
-        coff[q] = (unsigned)(MODE == 0 ? fb_idx(x, W - 1) : clampi(x, 0, W - 1));
-    }
-    float pre[NLD];
-#pragma unroll
-    for (int e = 0; e < NLD; ++e) pre[e] = src[roff[e / 3] + coff[e % 3]];
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-#pragma unroll
-        for (int sidx = 0; sidx < TH / 8; ++sidx)
-#pragma unroll
-            for (int q = 0; q < 3; ++q) tin[(tid >> 5) + 8 * sidx][(tid & 31) + 32 * q] = pre[sidx * 3 + q];
-        __syncthreads();
-        if (p + 1 < NP) {
-            const float *sp = src + (size_t)(p + 1) * P;
-#pragma unroll
-            for (int e = 0; e < NLD; ++e) pre[e] = sp[roff[e / 3] + coff[e % 3]];
-        }
-        static_assert((BW_TY / 4) * TW % 256 == 0, "the vertical pass divides evenly over the workgroup");
-#pragma unroll 1
-        for (int i = tid; i < (BW_TY / 4) * TW; i += 256) {
-            const int rg = i / TW, col = i - rg * TW;
-            float w[36];
-#pragma unroll
-            for (int t = 0; t < 36; ++t) w[t] = tin[rg * 4 + t][col];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float acc = MODE == 0 ? w[KSH + r] * taps.k[0] : w[KSH + r];
-#pragma unroll
-                for (int j = 1; j <= KSH; ++j) {
-                    float sm = w[KSH + r - j] + w[KSH + r + j];
-                    acc += MODE == 0 ? sm * taps.k[j] : sm;
-                }
-                tv[rg * 4 + r][col] = acc;
-            }
-        }
-        __syncthreads();
-#pragma unroll 1
-        for (int h = 0; h < NR; ++h) {
-            asm volatile("" ::: "memory");      // one row's window at a time in registers
-            float c[36];
-            const float4 *row4 = reinterpret_cast<const float4 *>(&tv[ly + 16 * h][4 * xg]);
-#pragma unroll
-            for (int q = 0; q < 9; ++q) { float4 v = row4[q]; c[4 * q] = v.x; c[4 * q + 1] = v.y; c[4 * q + 2] = v.z; c[4 * q + 3] = v.w; }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float acc = MODE == 0 ? c[KSH + k] * taps.k[0] : c[KSH + k];
-#pragma unroll
-                for (int i = 1; i <= KSH; ++i) {
-                    float sm = c[KSH + k - i] + c[KSH + k + i];
-                    acc += MODE == 0 ? sm * taps.k[i] : sm;
-                }
-                res[p][h][k] = acc;
-            }
-        }
-        // next plane: tin is rewritten before, tv after the barrier that follows the tin load
-    }
-    const float box_inv = 1.f / ((1 + 2 * KSH) * (1 + 2 * KSH));
-    const int x0 = bx + 4 * xg;
-    // UM: the displacements of the tile go through LDS (the source tile's space: every thread is past its last read of
-    // it), so that the per-pixel step after them runs with one pixel per lane along rows (coalesced gathers and stores)
-    float (*tf)[BW_TY][BL_TX] = reinterpret_cast<float (*)[BW_TY][BL_TX]>(&tin[0][0]);
-    static_assert(sizeof(float) * 2 * BW_TY * BL_TX <= sizeof(float) * TH * TW, "the displacement tile fits in the source tile");
-#pragma unroll
-    for (int h = 0; h < NR; ++h) {
-        const int y = by + ly + 16 * h;
-        if (y >= H) continue;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            int x = x0 + k;
-            if (x >= W) continue;
-            size_t o = (size_t)y * W + x;
-            float v[NP];
-#pragma unroll
-            for (int p = 0; p < NP; ++p) v[p] = MODE == 0 ? res[p][h][k] : res[p][h][k] * box_inv;
-            if (FLOW) {
-                float g11 = v[0], g12 = v[NP > 1 ? 1 : 0], g22 = v[NP > 2 ? 2 : 0], h1 = v[NP > 3 ? 3 : 0], h2 = v[NP > 4 ? 4 : 0];
-                float detInv = 1.f / (g11 * g22 - g12 * g12 + 1e-3f);
-                const float ux = (g11 * h2 - g12 * h1) * detInv, uy = (g22 * h1 - g12 * h2) * detInv;
-                if (UM) { tf[0][ly + 16 * h][4 * xg + k] = ux; tf[1][ly + 16 * h][4 * xg + k] = uy; }
-                else { flowx[o] = ux; flowy[o] = uy; }
-            } else {
-#pragma unroll
-                for (int p = 0; p < NP; ++p) dst[p * P + o] = v[p];
-            }
-        }
-    }
-    if (FLOW && UM) {
-        __syncthreads();
-#pragma unroll 2
-        for (int j = 0; j < BW_TY / 4; ++j) {
-            const int ry = (tid >> 6) + 4 * j, rx = tid & 63, y = by + ry, x = bx + rx;
-            if (y >= H || x >= W) continue;
-            const float ux = tf[0][ry][rx], uy = tf[1][ry][rx];
-            if (flowx) { flowx[(size_t)y * W + x] = ux; flowy[(size_t)y * W + x] = uy; }
-            fb_matrices_at(x, y, ux, uy, R0, R1, Mnext, H, W);
-        }
-    }
-}
-
-template <int NP, int MODE, bool FLOW>
-static int fb_window_launch(ofri_ctx *ctx, const float *src, float *dst, float *fx, float *fy, int rows, int cols,
-                            const float *taps_host, int ksh) {
-    OFRI_TRY(ofri_check_ctx(ctx));
-    OFRI_REQUIRE(src && (FLOW ? (fx && fy) : dst != nullptr), "null pointer");
-    OFRI_REQUIRE(rows > 0 && cols > 0, "bad shape");
-    OFRI_REQUIRE(ksh >= 0 && ksh <= FB_MAX_KSH, "ksize_half out of range (0..%d)", FB_MAX_KSH);
-    OFRI_REQUIRE(MODE == 1 || taps_host, "null taps");
-    OFRI_REQUIRE(src != dst, "window filter cannot run in place");
-    FbTaps t;
-    memset(&t, 0, sizeof(t));
-    if (MODE == 0) memcpy(t.k, taps_host, (ksh + 1) * sizeof(float));
-    if (ksh == 16 && (size_t)rows * cols < 0xffffffffull) {
-        dim3 g16(ceil_div(cols, BL_TX), ceil_div(rows, BW_TY));
-        k_fb_window16<NP, MODE, FLOW><<<g16, 256, 0, ctx->stream>>>(src, dst, fx, fy, rows, cols, t);
-        OFRI_LAUNCH_CHECK();
-        return OFRI_OK;
-    }
-    size_t lds = ((size_t)(BL_TY + 2 * ksh) * (BL_TX + 2 * ksh) + (size_t)BL_TY * (BL_TX + 2 * ksh)) * sizeof(float);
-    OFRI_REQUIRE(lds <= 160 * 1024, "window too large for LDS");
-    auto kern = k_fb_window<NP, MODE, FLOW>;
-    if (lds > 64 * 1024) OFRI_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    dim3 b(64, 4), g(ceil_div(cols, BL_TX), ceil_div(rows, BL_TY));
-    kern<<<g, b, lds, ctx->stream>>>(src, dst, fx, fy, rows, cols, ksh, t);
-    OFRI_LAUNCH_CHECK();
-    return OFRI_OK;
-}
-
-extern "C" int ofri_fb_blur(ofri_ctx *ctx, const float *src, float *dst, int rows, int cols,
-                            const float *half_taps_host, int ksize_half) {
-    return fb_window_launch<1, 0, false>(ctx, src, dst, nullptr, nullptr, rows, cols, half_taps_host, ksize_half);
-}
-extern "C" int ofri_fb_blur5(ofri_ctx *ctx, const float *src5, float *dst5, int rows, int cols,
-                             const float *half_taps_host, int ksize_half) {
-    return fb_window_launch<5, 0, false>(ctx, src5, dst5, nullptr, nullptr, rows, cols, half_taps_host, ksize_half);
-}
-extern "C" int ofri_fb_box5(ofri_ctx *ctx, const float *src5, float *dst5, int rows, int cols, int ksize_half) {
-    return fb_window_launch<5, 1, false>(ctx, src5, dst5, nullptr, nullptr, rows, cols, nullptr, ksize_half);
-}
-extern "C" int ofri_fb_window5_update_flow(ofri_ctx *ctx, const float *M5, float *flowx, float *flowy, int rows, int cols,
-                                           const float *half_taps_host, int ksize_half, int box) {
-    if (box) return fb_window_launch<5, 1, true>(ctx, M5, nullptr, flowx, flowy, rows, cols, nullptr, ksize_half);
-    return fb_window_launch<5, 0, true>(ctx, M5, nullptr, flowx, flowy, rows, cols, half_taps_host, ksize_half);
-}
-
-__global__ void k_fb_update_matrices(const float *__restrict__ flowx, const float *__restrict__ flowy,
-                                     const float *__restrict__ R0, const float *__restrict__ R1, float *__restrict__ M,
-                                     int H, int W) {
-    int x = blockIdx.x * blockDim.x + threadIdx.x;
-    int y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= W || y >= H) return;
-    const size_t o = (size_t)y * W + x;
-    fb_matrices_at(x, y, flowx[o], flowy[o], R0, R1, M, H, W);
-}
-
-extern "C" int ofri_fb_update_matrices(ofri_ctx *ctx, const float *flowx, const float *flowy, const float *R0,
-                                       const float *R1, float *M, int rows, int cols) {
-    OFRI_TRY(ofri_check_ctx(ctx));
-    OFRI_REQUIRE(flowx && flowy && R0 && R1 && M, "null pointer");
-    OFRI_REQUIRE(rows > 0 && cols > 0, "bad shape");
-    dim3 b(64, 4), g(ceil_div(cols, 64), ceil_div(rows, 4));
-    k_fb_update_matrices<<<g, b, 0, ctx->stream>>>(flowx, flowy, R0, R1, M, rows, cols);
-    OFRI_LAUNCH_CHECK();
-    return OFRI_OK;
-}
-
-// One iteration of the reference's flow loop from the second on (Farneback_PyCL.py:442-457): window filter of the matrices
-// + 2x2 solve + the next matrices in one launch for the default window (ksize_half 16, Gaussian or box); otherwise the
-// separate steps.  flowx, flowy may be null when the displacement of this iteration is not wanted (the fused launch then
-// does not store it); M5_next must not be M5.
-extern "C" int ofri_fb_window5_flow_matrices(ofri_ctx *ctx, const float *M5, float *flowx, float *flowy, const float *R0,
-                                             const float *R1, float *M5_next, int rows, int cols,
-                                             const float *half_taps_host, int ksize_half, int box) {
-    OFRI_TRY(ofri_check_ctx(ctx));
-    OFRI_REQUIRE(M5 && R0 && R1 && M5_next && M5_next != M5, "null or aliased pointer");
-    OFRI_REQUIRE((flowx == nullptr) == (flowy == nullptr), "flowx and flowy must both be given or both be null");
-    OFRI_REQUIRE(rows > 0 && cols > 0, "bad shape");
-    OFRI_REQUIRE(box || half_taps_host, "null taps");
-    if (ksize_half == 16 && (size_t)rows * cols < 0xffffffffull) {
-        FbTaps t;
-        memset(&t, 0, sizeof(t));
-        if (!box) memcpy(t.k, half_taps_host, 17 * sizeof(float));
-        dim3 g16(ceil_div(cols, BL_TX), ceil_div(rows, BW_TY));
-        if (box) k_fb_window16<5, 1, true, true><<<g16, 256, 0, ctx->stream>>>(M5, nullptr, flowx, flowy, rows, cols, t, R0, R1, M5_next);
-        else k_fb_window16<5, 0, true, true><<<g16, 256, 0, ctx->stream>>>(M5, nullptr, flowx, flowy, rows, cols, t, R0, R1, M5_next);
-        OFRI_LAUNCH_CHECK();
-        return OFRI_OK;
-    }
-    PoolBuf tx(ctx), ty(ctx);
-    if (!flowx) {
-        OFRI_TRY(tx.get((size_t)rows * cols * sizeof(float))); OFRI_TRY(ty.get((size_t)rows * cols * sizeof(float)));
-        flowx = tx.as<float>(); flowy = ty.as<float>();
-    }
-    OFRI_TRY(ofri_fb_window5_update_flow(ctx, M5, flowx, flowy, rows, cols, half_taps_host, ksize_half, box));
-    return ofri_fb_update_matrices(ctx, flowx, flowy, R0, R1, M5_next, rows, cols);
-}
-
-// gaussianBlur followed by polynomialExpansion of the blurred image (same size): one launch for the 3-tap blur
-// (ksize_half 1, the reference's pre-blur with one internal pyramid level), the two steps otherwise.
 extern "C" int ofri_fb_blur_polyexp(ofri_ctx *ctx, const float *src, float *dst5, int rows, int cols,
                                     const float *blur_half_taps_host, int ksize_half, int polyN, const float *g_host,
                                     const float *xg_host, const float *xxg_host, const float *ig_host) {
-    OFRI_TRY(ofri_check_ctx(ctx));
-    OFRI_REQUIRE(src && dst5 && blur_half_taps_host && g_host && xg_host && xxg_host && ig_host, "null pointer");
-    OFRI_REQUIRE(rows > 0 && cols > 0, "bad shape");
-    OFRI_REQUIRE(polyN == 5 || polyN == 7, "polyN must be 5 or 7");
-    if (ksize_half != 1) {
-        PoolBuf tmp(ctx);
-        OFRI_TRY(tmp.get((size_t)rows * cols * sizeof(float)));
-        OFRI_TRY(ofri_fb_blur(ctx, src, tmp.as<float>(), rows, cols, blur_half_taps_host, ksize_half));
-        return ofri_fb_polyexp(ctx, tmp.as<float>(), dst5, rows, cols, polyN, g_host, xg_host, xxg_host, ig_host);
-    }
-    FbPoly c;
-    memset(&c, 0, sizeof(c));
-    memcpy(c.g, g_host, (polyN + 1) * sizeof(float));
-    memcpy(c.xg, xg_host, (polyN + 1) * sizeof(float));
-    memcpy(c.xxg, xxg_host, (polyN + 1) * sizeof(float));
-    memcpy(c.ig, ig_host, 4 * sizeof(float));
-    dim3 g(ceil_div(cols, BP_TX), ceil_div(rows, BP_TY));
-    if (polyN == 5) k_fb_blur3_polyexp<5><<<g, 256, 0, ctx->stream>>>(src, dst5, rows, cols, blur_half_taps_host[0], blur_half_taps_host[1], c);
-    else k_fb_blur3_polyexp<7><<<g, 256, 0, ctx->stream>>>(src, dst5, rows, cols, blur_half_taps_host[0], blur_half_taps_host[1], c);
-    OFRI_LAUNCH_CHECK();
-    return OFRI_OK;
+    return FB_DISPATCH(ctx, fbk_blur_polyexp(ctx, src, dst5, rows, cols, blur_half_taps_host, ksize_half, polyN, g_host, xg_host, xxg_host, ig_host));
 }
-
-// ---- updateFlow (.cl:408-429) -----------------------------------------------------------------------
-__global__ void k_fb_update_flow(const float *__restrict__ M, float *__restrict__ flowx, float *__restrict__ flowy, size_t P) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, st = (size_t)gridDim.x * blockDim.x;
-    for (; i < P; i += st) {
-        float g11 = M[i], g12 = M[P + i], g22 = M[2 * P + i], h1 = M[3 * P + i], h2 = M[4 * P + i];
-        float detInv = 1.f / (g11 * g22 - g12 * g12 + 1e-3f);
-        flowx[i] = (g11 * h2 - g12 * h1) * detInv;
-        flowy[i] = (g22 * h1 - g12 * h2) * detInv;
-    }
+extern "C" int ofri_fb_blur(ofri_ctx *ctx, const float *src, float *dst, int rows, int cols,
+                            const float *half_taps_host, int ksize_half) {
+    return FB_DISPATCH(ctx, fbk_blur(ctx, src, dst, rows, cols, half_taps_host, ksize_half));
+}
+extern "C" int ofri_fb_blur5(ofri_ctx *ctx, const float *src5, float *dst5, int rows, int cols,
+                             const float *half_taps_host, int ksize_half) {
+    return FB_DISPATCH(ctx, fbk_blur5(ctx, src5, dst5, rows, cols, half_taps_host, ksize_half));
+}
+extern "C" int ofri_fb_box5(ofri_ctx *ctx, const float *src5, float *dst5, int rows, int cols, int ksize_half) {
+    return FB_DISPATCH(ctx, fbk_box5(ctx, src5, dst5, rows, cols, ksize_half));
+}
+extern "C" int ofri_fb_update_matrices(ofri_ctx *ctx, const float *flowx, const float *flowy, const float *R0,
+                                       const float *R1, float *M, int rows, int cols) {
+    return FB_DISPATCH(ctx, fbk_update_matrices(ctx, flowx, flowy, R0, R1, M, rows, cols));
 }
 extern "C" int ofri_fb_update_flow(ofri_ctx *ctx, const float *M, float *flowx, float *flowy, int rows, int cols) {
-    OFRI_TRY(ofri_check_ctx(ctx));
-    OFRI_REQUIRE(M && flowx && flowy, "null pointer");
-    OFRI_REQUIRE(rows > 0 && cols > 0, "bad shape");
-    size_t P = (size_t)rows * cols, g = (P + 255) / 256;
-    if (g > 4096) g = 4096;
-    k_fb_update_flow<<<(int)g, 256, 0, ctx->stream>>>(M, flowx, flowy, P);
-    OFRI_LAUNCH_CHECK();
-    return OFRI_OK;
+    return FB_DISPATCH(ctx, fbk_update_flow(ctx, M, flowx, flowy, rows, cols));
+}
+extern "C" int ofri_fb_window5_update_flow(ofri_ctx *ctx, const float *M5, float *flowx, float *flowy, int rows, int cols,
+                                           const float *half_taps_host, int ksize_half, int box) {
+    return FB_DISPATCH(ctx, fbk_window5_update_flow(ctx, M5, flowx, flowy, rows, cols, half_taps_host, ksize_half, box));
+}
+extern "C" int ofri_fb_window5_flow_matrices(ofri_ctx *ctx, const float *M5, float *flowx, float *flowy, const float *R0,
+                                             const float *R1, float *M5_next, int rows, int cols,
+                                             const float *half_taps_host, int ksize_half, int box) {
+    return FB_DISPATCH(ctx, fbk_window5_flow_matrices(ctx, M5, flowx, flowy, R0, R1, M5_next, rows, cols, half_taps_host, ksize_half, box));
 }
