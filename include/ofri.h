@@ -247,6 +247,13 @@ int ofri_fb_window5_flow_matrices(ofri_ctx *ctx, const float *M5, float *flowx, 
 int ofri_lk_compute(ofri_ctx *ctx, const float *im1, const float *im2, const float *U_in,
                     const float *V_in, float *U_out, float *V_out, int rows, int cols, int niter,
                     int half_window, int asym_left, int asym_right, int asym_top, int asym_bottom);
+/*   mode = 0   fast (default): for the 27 x 27 window of the reference's examples (half_window 13, no asymmetry flags) a
+ *              tile of 32 x 16 pixels per workgroup shares the staged images and gradients, a lane sums its own pixels'
+ *              windows serially and interpolates the second image separably; pixels whose displaced window leaves the
+ *              staged neighbourhood (more than 6 pixels from the tile's central displacement) are redone by the exact
+ *              kernel.  Agrees with the exact mode to about 1e-5 px.  Other windows use the exact kernel.
+ *   mode = -1  exact: one wavefront per pixel in the reference's lane layout and reduction order (.cl:304-669). */
+int ofri_lk_set_mode(ofri_ctx *ctx, int mode);
 
 /* ---- pyramid glue --------------------------------------------------------------------------- */
 /* imresize (src/GenericPyramidalOpticalFlow.py:67-68): Pillow's scale-aware bicubic (a = -0.5) on

@@ -79,6 +79,7 @@ _PROTOS = {
     "ofri_fb_window5_update_flow": ([_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i], _i),
     "ofri_fb_window5_flow_matrices": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i], _i),
     "ofri_lk_compute": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i], _i),
+    "ofri_lk_set_mode": ([_vp, _i], _i),
     "ofri_resize_bicubic": ([_vp, _vp, _i, _i, _vp, _i, _i], _i),
     "ofri_resize_bilinear": ([_vp, _vp, _i, _i, _vp, _i, _i], _i),
     "ofri_spline_upsample": ([_vp, _vp, _i, _i, _vp, _i, _i, _f], _i),
@@ -230,6 +231,9 @@ class Context(object):
 
     def set_fb_mode(self, mode):
         check(lib().ofri_fb_set_mode(self._h, int(mode)))
+
+    def set_lk_mode(self, mode):
+        check(lib().ofri_lk_set_mode(self._h, int(mode)))
 
     def set_ls_mode(self, mode):
         check(lib().ofri_ls_set_mode(self._h, int(mode)))

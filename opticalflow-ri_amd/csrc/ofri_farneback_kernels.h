@@ -285,14 +285,19 @@ k_fb_window(const float *__restrict__ src, float *__restrict__ dst, float *__res
 template <int NP, int MODE, bool FLOW, bool UM = false>
 __global__ void __launch_bounds__(256)
 k_fb_window16(const float *__restrict__ src, float *__restrict__ dst, float *__restrict__ flowx, float *__restrict__ flowy,
-              int H, int W, FbTaps taps, const float *__restrict__ R0 = nullptr, const float *__restrict__ R1 = nullptr,
-              float *__restrict__ Mnext = nullptr) {
+              int H, int W, FbTaps taps, int tiles_x, int ntiles, const float *__restrict__ R0 = nullptr,
+              const float *__restrict__ R1 = nullptr, float *__restrict__ Mnext = nullptr) {
     constexpr int KSH = 16, TW = BL_TX + 2 * KSH, TH = BW_TY + 2 * KSH;      // 96 x 64
     constexpr int NLD = TH / 8 * 3;                                          // loads per thread and plane
     constexpr int NR = BW_TY / 16;                                           // output rows per thread
     __shared__ float tin[TH][TW];
     __shared__ __attribute__((aligned(16))) float tv[BW_TY][TW];
-    const int bx = blockIdx.x * BL_TX, by = blockIdx.y * BW_TY, tid = threadIdx.x;
+    // Workgroups go to the 8 XCDs round-robin by index and every XCD has its own L2: give each XCD a contiguous run of
+    // tiles in raster order, so that the tiles whose 16-pixel aprons overlap are in flight on the same L2 (a tile reads
+    // three times its own area; without this every apron came from memory again)
+    const int b = blockIdx.x, q8 = ntiles >> 3, r8 = ntiles & 7, xcd = b & 7;
+    const int t = xcd * q8 + (xcd < r8 ? xcd : r8) + (b >> 3);
+    const int bx = (t % tiles_x) * BL_TX, by = (t / tiles_x) * BW_TY, tid = threadIdx.x;
     const size_t P = (size_t)H * W;
     const int ly = tid >> 4, xg = tid & 15;                                  // horizontal pass: row (and row + 16), group of 4 columns
     float res[NP][NR][4];
@@ -367,31 +372,51 @@ k_fb_window16(const float *__restrict__ src, float *__restrict__ dst, float *__r
     }
     const float box_inv = 1.f / ((1 + 2 * KSH) * (1 + 2 * KSH));
     const int x0 = bx + 4 * xg;
+    const bool vec_ok = FLOW ? (UM || ((((size_t)flowx | (size_t)flowy) & 15) == 0)) : ((((size_t)dst) & 15) == 0);
     // UM: the displacements of the tile go through LDS (the source tile's space: every thread is past its last read of
     // it), so that the per-pixel step after them runs with one pixel per lane along rows (coalesced gathers and stores)
     float (*tf)[BW_TY][BL_TX] = reinterpret_cast<float (*)[BW_TY][BL_TX]>(&tin[0][0]);
     static_assert(sizeof(float) * 2 * BW_TY * BL_TX <= sizeof(float) * TH * TW, "the displacement tile fits in the source tile");
+    const bool vec4 = (W & 3) == 0 && vec_ok;     // a thread's four pixels are one aligned 16-byte group
 #pragma unroll
     for (int h = 0; h < NR; ++h) {
         const int y = by + ly + 16 * h;
         if (y >= H) continue;
+        float ox[4], oy[4], ov[NP][4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            int x = x0 + k;
-            if (x >= W) continue;
-            size_t o = (size_t)y * W + x;
             float v[NP];
 #pragma unroll
-            for (int p = 0; p < NP; ++p) v[p] = MODE == 0 ? res[p][h][k] : res[p][h][k] * box_inv;
+            for (int p = 0; p < NP; ++p) { v[p] = MODE == 0 ? res[p][h][k] : res[p][h][k] * box_inv; ov[p][k] = v[p]; }
             if (FLOW) {
                 float g11 = v[0], g12 = v[NP > 1 ? 1 : 0], g22 = v[NP > 2 ? 2 : 0], h1 = v[NP > 3 ? 3 : 0], h2 = v[NP > 4 ? 4 : 0];
                 float detInv = 1.f / (g11 * g22 - g12 * g12 + 1e-3f);
-                const float ux = (g11 * h2 - g12 * h1) * detInv, uy = (g22 * h1 - g12 * h2) * detInv;
-                if (UM) { tf[0][ly + 16 * h][4 * xg + k] = ux; tf[1][ly + 16 * h][4 * xg + k] = uy; }
-                else { flowx[o] = ux; flowy[o] = uy; }
+                ox[k] = (g11 * h2 - g12 * h1) * detInv; oy[k] = (g22 * h1 - g12 * h2) * detInv;
+            }
+        }
+        if (FLOW && UM) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { tf[0][ly + 16 * h][4 * xg + k] = ox[k]; tf[1][ly + 16 * h][4 * xg + k] = oy[k]; }
+        } else if (vec4 && x0 + 3 < W) {
+            const size_t o = (size_t)y * W + x0;
+            if (FLOW) {
+                *reinterpret_cast<float4 *>(flowx + o) = make_float4(ox[0], ox[1], ox[2], ox[3]);
+                *reinterpret_cast<float4 *>(flowy + o) = make_float4(oy[0], oy[1], oy[2], oy[3]);
             } else {
 #pragma unroll
-                for (int p = 0; p < NP; ++p) dst[p * P + o] = v[p];
+                for (int p = 0; p < NP; ++p) *reinterpret_cast<float4 *>(dst + p * P + o) = make_float4(ov[p][0], ov[p][1], ov[p][2], ov[p][3]);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int x = x0 + k;
+                if (x >= W) continue;
+                const size_t o = (size_t)y * W + x;
+                if (FLOW) { flowx[o] = ox[k]; flowy[o] = oy[k]; }
+                else {
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) dst[p * P + o] = ov[p][k];
+                }
             }
         }
     }
@@ -421,8 +446,8 @@ static int fb_window_launch(ofri_ctx *ctx, const float *src, float *dst, float *
     memset(&t, 0, sizeof(t));
     if (MODE == 0) memcpy(t.k, taps_host, (ksh + 1) * sizeof(float));
     if (ksh == 16 && (size_t)rows * cols < 0xffffffffull) {
-        dim3 g16(ceil_div(cols, BL_TX), ceil_div(rows, BW_TY));
-        k_fb_window16<NP, MODE, FLOW><<<g16, 256, 0, ctx->stream>>>(src, dst, fx, fy, rows, cols, t);
+        const int tx16 = ceil_div(cols, BL_TX), nt16 = tx16 * ceil_div(rows, BW_TY);
+        k_fb_window16<NP, MODE, FLOW><<<nt16, 256, 0, ctx->stream>>>(src, dst, fx, fy, rows, cols, t, tx16, nt16);
         OFRI_LAUNCH_CHECK();
         return OFRI_OK;
     }
@@ -490,9 +515,9 @@ static int fbk_window5_flow_matrices(ofri_ctx *ctx, const float *M5, float *flow
         FbTaps t;
         memset(&t, 0, sizeof(t));
         if (!box) memcpy(t.k, half_taps_host, 17 * sizeof(float));
-        dim3 g16(ceil_div(cols, BL_TX), ceil_div(rows, BW_TY));
-        if (box) k_fb_window16<5, 1, true, true><<<g16, 256, 0, ctx->stream>>>(M5, nullptr, flowx, flowy, rows, cols, t, R0, R1, M5_next);
-        else k_fb_window16<5, 0, true, true><<<g16, 256, 0, ctx->stream>>>(M5, nullptr, flowx, flowy, rows, cols, t, R0, R1, M5_next);
+        const int tx16 = ceil_div(cols, BL_TX), nt16 = tx16 * ceil_div(rows, BW_TY);
+        if (box) k_fb_window16<5, 1, true, true><<<nt16, 256, 0, ctx->stream>>>(M5, nullptr, flowx, flowy, rows, cols, t, tx16, nt16, R0, R1, M5_next);
+        else k_fb_window16<5, 0, true, true><<<nt16, 256, 0, ctx->stream>>>(M5, nullptr, flowx, flowy, rows, cols, t, tx16, nt16, R0, R1, M5_next);
         OFRI_LAUNCH_CHECK();
         return OFRI_OK;
     }

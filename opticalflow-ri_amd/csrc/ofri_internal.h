@@ -16,6 +16,7 @@ struct ofri_ctx {
     bool owns_stream = false;
     int hs_fuse = 0;                                   // sweeps per launch, 0 = automatic
     int fb_mode = 0;                                   // Farneback: 0 fast (fused multiply-adds), -1 exact (separately rounded)
+    int lk_mode = 0;                                   // dense LK: 0 fast (tile kernel where it applies), -1 exact
     int ls_mode = 0;                                   // Liu-Shen: 0 automatic, 1 one sweep per launch, 6 / 8 pipeline depth, -1 exact
     int ncu = 0;                                       // compute units of the device (0 = not queried yet)
     std::map<size_t, std::vector<void *>> pool;        // free blocks by rounded size

@@ -55,21 +55,13 @@ __device__ __forceinline__ float lk_sample(const float *__restrict__ J, const Lk
            (x.w1 * y.w1) * lk_at(J, y.i1 + x.i1);
 }
 
-__global__ void __launch_bounds__(64 * LK_PX)
-k_lk_dense(const float *__restrict__ I, const float *__restrict__ J, const float *__restrict__ Uin,
-           const float *__restrict__ Vin, float *__restrict__ Uout, float *__restrict__ Vout, int H, int W, LkParams p) {
-    __shared__ float tile[LK_TH][LK_TW + 1];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+// One pixel (i, j) by one wavefront.  tile: the staged first image, tile[ly][lx] = I at (i - half_y - 1 + ly,
+// j0 - half_x - 1 + lx) edge clamped, where j0 = j - wv (several pixels of a row may share a tile).
+template <int TWP>
+__device__ __forceinline__ void lk_pixel(const float (*tile)[TWP], const float *__restrict__ J, const float *__restrict__ Uin,
+                                         const float *__restrict__ Vin, float *__restrict__ Uout, float *__restrict__ Vout, int H, int W,
+                                         const LkParams &p, int i, int j, int wv, int lane) {
     const int xid = lane & 7, yid = lane >> 3;
-    const int i = blockIdx.y, j0 = blockIdx.x * LK_PX, j = j0 + wv;
-    // tile origin = (first pixel - halfWin - 1): 34 x 34 samples per pixel at integer positions, edge clamped
-    for (int t = tid; t < LK_TH * LK_TW; t += 64 * LK_PX) {
-        int ly = t / LK_TW, lx = t - ly * LK_TW;
-        int yy = clampi(i - p.half_y - 1 + ly, 0, H - 1), xx = clampi(j0 - p.half_x - 1 + lx, 0, W - 1);
-        tile[ly][lx] = I[(size_t)yy * W + xx];
-    }
-    __syncthreads();
-    if (j >= W) return;                         // whole wavefront; no workgroup barrier follows
     const size_t gid = (size_t)i * W + j;
 
     // per-lane weights of the four sample columns and rows (.cl:339-374)
@@ -155,6 +147,258 @@ k_lk_dense(const float *__restrict__ I, const float *__restrict__ J, const float
     }
 }
 
+__global__ void __launch_bounds__(64 * LK_PX)
+k_lk_dense(const float *__restrict__ I, const float *__restrict__ J, const float *__restrict__ Uin,
+           const float *__restrict__ Vin, float *__restrict__ Uout, float *__restrict__ Vout, int H, int W, LkParams p) {
+    __shared__ float tile[LK_TH][LK_TW + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int i = blockIdx.y, j0 = blockIdx.x * LK_PX, j = j0 + wv;
+    // tile origin = (first pixel - halfWin - 1): 34 x 34 samples per pixel at integer positions, edge clamped
+    for (int t = tid; t < LK_TH * LK_TW; t += 64 * LK_PX) {
+        int ly = t / LK_TW, lx = t - ly * LK_TW;
+        int yy = clampi(i - p.half_y - 1 + ly, 0, H - 1), xx = clampi(j0 - p.half_x - 1 + lx, 0, W - 1);
+        tile[ly][lx] = I[(size_t)yy * W + xx];
+    }
+    __syncthreads();
+    if (j >= W) return;                         // whole wavefront; no workgroup barrier follows
+    lk_pixel<LK_TW + 1>(tile, J, Uin, Vin, Uout, Vout, H, W, p, i, j, wv, lane);
+}
+
+// The pixels of a list (indices i * W + j, *count of them), one per wavefront with a tile of its own: those that the
+// tile kernel below could not finish inside its staged neighbourhood of the second image.
+__global__ void __launch_bounds__(64 * LK_PX)
+k_lk_list(const float *__restrict__ I, const float *__restrict__ J, const float *__restrict__ Uin, const float *__restrict__ Vin,
+          float *__restrict__ Uout, float *__restrict__ Vout, int H, int W, LkParams p, const unsigned *__restrict__ list,
+          const unsigned *__restrict__ count) {
+    __shared__ float tile[LK_PX][LK_TH][LK_TH + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const unsigned n = *count;
+    // every wavefront of the workgroup makes the same number of rounds, so the barriers match
+    for (unsigned base = blockIdx.x * LK_PX; base < n; base += gridDim.x * LK_PX) {
+        const unsigned e = base + wv;
+        const bool have = e < n;
+        const unsigned gid = have ? list[e] : 0u;
+        const int i = (int)(gid / (unsigned)W), j = (int)(gid - (unsigned)i * (unsigned)W);
+        __syncthreads();                        // the round before is done with the tiles
+        if (have)
+            for (int t = lane; t < LK_TH * LK_TH; t += 64) {
+                int ly = t / LK_TH, lx = t - ly * LK_TH;
+                int yy = clampi(i - p.half_y - 1 + ly, 0, H - 1), xx = clampi(j - p.half_x - 1 + lx, 0, W - 1);
+                tile[wv][ly][lx] = I[(size_t)yy * W + xx];
+            }
+        __syncthreads();
+        if (have) lk_pixel<LK_TH + 1>(tile[wv], J, Uin, Vin, Uout, Vout, H, W, p, i, j, 0, lane);
+    }
+}
+
+// ---- tile of pixels (fast mode, 27 x 27 window) -------------------------------------------------------------------
+// A 256-thread workgroup owns 32 x 16 pixels, a lane two vertically adjacent ones.  What neighbouring pixels share is
+// made once per tile in LDS: the first image around the tile (58 x 42 window samples: a pixel's sample (oy, ox) is the
+// image at pixel - 13 + (oy, ox), edge clamped), its Scharr gradients, and the second image around the tile displaced
+// by the tile's central displacement, with a margin of LKT_R pixels for the other pixels' displacements and the Newton
+// steps (edge clamped as well, so the sampler's clamp-to-edge needs no test in the loop).  A lane then walks its pixels'
+// 729 window samples serially - no reduction across lanes: sums A11, A12, A22 first, then up to `iters` Newton steps,
+// each b = sum over the window of (J(sample + displacement) - I(sample)) * (Dx, Dy).  All samples of a pixel share one
+// pair of bilinear weights (the displacement's fractions), so J is interpolated separably: along x as the row is read
+// (each texel is read once per row), along y against the row before, kept in 27 registers per pixel.  The two pixels of
+// a lane share every read of I, Dx, Dy (pixel 1's sample row oy is pixel 0's row oy + 1).  A pixel whose displaced
+// window leaves the staged neighbourhood is put on a list and done afterwards by k_lk_list from its input
+// displacement.  Sums run in another order than the reference's lane tree and the interpolation is factored, so
+// results agree with the exact kernel to rounding (about 1e-5 px), not bit for bit.
+#define LKT_PX 32
+#define LKT_PY 16
+#define LKT_WIN 27
+#define LKT_HW 13
+#define LKT_R 6
+#define LKT_SW (LKT_PX + LKT_WIN - 1)            // 58 sample columns
+#define LKT_SH (LKT_PY + LKT_WIN - 1)            // 42 sample rows
+#define LKT_SP 60                                // their row pitch
+#define LKT_JW (LKT_SW + 1 + 2 * LKT_R)          // 71 columns of the second image
+#define LKT_JH (LKT_SH + 1 + 2 * LKT_R)          // 55 rows
+#define LKT_JP 73                                // their row pitch
+static_assert((LKT_SH + 2) * (LKT_SW + 2) <= LKT_JH * LKT_JP, "the first image with its gradient apron is staged where the second image goes later");
+
+__device__ __forceinline__ int lk_to_int(float f) { return (int)fminf(fmaxf(f, -1.0e9f), 1.0e9f); }
+
+struct LktPix {                  // Newton state of one pixel
+    float ppx, ppy, A11, A12, A22, b1, b2, ax, ay;
+    int joff;                    // offset of the window's first texel in the staged second image; < 0: not iterating
+    bool live;                   // still iterating
+};
+
+__global__ void __launch_bounds__(256, 3)
+k_lk_tile(const float *__restrict__ I, const float *__restrict__ J, const float *__restrict__ Uin, const float *__restrict__ Vin,
+          float *__restrict__ Uout, float *__restrict__ Vout, int H, int W, int iters, int tiles_x, unsigned *__restrict__ list,
+          unsigned *__restrict__ count) {
+    __shared__ float sI[LKT_SH][LKT_SP], sDx[LKT_SH][LKT_SP], sDy[LKT_SH][LKT_SP];
+    __shared__ float sJ[LKT_JH * LKT_JP];
+    __shared__ int centre[2];
+    const int tid = threadIdx.x;
+    const int tx0 = (blockIdx.x % tiles_x) * LKT_PX, ty0 = (blockIdx.x / tiles_x) * LKT_PY;
+    // ---- first image with a one-pixel apron (in sJ's space), then gradients
+    {
+        float (*tI)[LKT_SW + 2] = reinterpret_cast<float (*)[LKT_SW + 2]>(sJ);
+        for (int t = tid; t < (LKT_SH + 2) * (LKT_SW + 2); t += 256) {
+            const int ly = t / (LKT_SW + 2), lx = t - ly * (LKT_SW + 2);
+            const int yy = clampi(ty0 - LKT_HW - 1 + ly, 0, H - 1), xx = clampi(tx0 - LKT_HW - 1 + lx, 0, W - 1);
+            tI[ly][lx] = I[(size_t)yy * W + xx];
+        }
+        if (tid == 0) {         // the tile's central pixel (clamped into the image) gives the neighbourhood's displacement
+            const size_t c = (size_t)min(ty0 + LKT_PY / 2, H - 1) * W + min(tx0 + LKT_PX / 2, W - 1);
+            centre[0] = clampi(lk_to_int(floorf(Uin[c])), -(1 << 24), 1 << 24);
+            centre[1] = clampi(lk_to_int(floorf(Vin[c])), -(1 << 24), 1 << 24);
+        }
+        __syncthreads();
+        for (int t = tid; t < LKT_SH * LKT_SW; t += 256) {
+            const int sy = t / LKT_SW, sx = t - sy * LKT_SW;
+#define TV(dy, dx) tI[sy + 1 + (dy)][sx + 1 + (dx)]
+            const float gx = ((TV(-1, 1) + TV(1, 1)) - TV(-1, -1)) - TV(1, -1);
+            const float gy = ((TV(1, -1) + TV(1, 1)) - TV(-1, -1)) - TV(-1, 1);
+            sDx[sy][sx] = fmaf(gx, 3.0f, (TV(0, 1) - TV(0, -1)) * 10.0f);
+            sDy[sy][sx] = fmaf(gy, 3.0f, (TV(1, 0) - TV(-1, 0)) * 10.0f);
+            sI[sy][sx] = TV(0, 0);
+#undef TV
+        }
+        __syncthreads();
+    }
+    // ---- second image around the displaced tile
+    const int jx0 = tx0 - LKT_HW - LKT_R + centre[0], jy0 = ty0 - LKT_HW - LKT_R + centre[1];
+    for (int t = tid; t < LKT_JH * LKT_JW; t += 256) {
+        const int ly = t / LKT_JW, lx = t - ly * LKT_JW;
+        const int yy = clampi(jy0 + ly, 0, H - 1), xx = clampi(jx0 + lx, 0, W - 1);
+        sJ[ly * LKT_JP + lx] = J[(size_t)yy * W + xx];
+    }
+    __syncthreads();
+
+    // ---- this lane's two pixels: column px, rows py and py + 1 of the tile
+    const int px = tid & 31, py = (tid >> 5) * 2;
+    const int gx = tx0 + px, gy = ty0 + py;
+    const bool in0 = gx < W && gy < H, in1 = gx < W && gy + 1 < H;
+    const float *pI = &sI[py][px], *pDx = &sDx[py][px], *pDy = &sDy[py][px];
+    LktPix q[2];
+    q[0].A11 = q[0].A12 = q[0].A22 = q[1].A11 = q[1].A12 = q[1].A22 = 0.f;
+#pragma unroll 1
+    for (int sy = 0; sy <= LKT_WIN; ++sy) {
+        const bool use0 = sy < LKT_WIN, use1 = sy > 0;      // uniform
+#pragma unroll
+        for (int ox = 0; ox < LKT_WIN; ++ox) {
+            const float dx = pDx[sy * LKT_SP + ox], dy = pDy[sy * LKT_SP + ox];
+            if (use0) { q[0].A11 = fmaf(dx, dx, q[0].A11); q[0].A12 = fmaf(dx, dy, q[0].A12); q[0].A22 = fmaf(dy, dy, q[0].A22); }
+            if (use1) { q[1].A11 = fmaf(dx, dx, q[1].A11); q[1].A12 = fmaf(dx, dy, q[1].A12); q[1].A22 = fmaf(dy, dy, q[1].A22); }
+        }
+    }
+    const float hw = (float)LKT_HW;
+    float u0[2], v0[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const bool in = k ? in1 : in0;
+        const size_t gid = (size_t)(gy + k) * W + gx;
+        u0[k] = in ? Uin[gid] : 0.f; v0[k] = in ? Vin[gid] : 0.f;
+        const float D = fmaf(q[k].A11, q[k].A22, -(q[k].A12 * q[k].A12));
+        q[k].live = in && !(D < 1.192092896e-07f);
+        if (in && !q[k].live) { Uout[gid] = u0[k]; Vout[gid] = v0[k]; }         // flat window: the displacement is left untouched
+        q[k].A11 /= D; q[k].A12 /= D; q[k].A22 /= D;
+        q[k].ppx = ((float)gx + u0[k]) - hw; q[k].ppy = ((float)(gy + k) + v0[k]) - hw;
+        q[k].joff = -1;
+    }
+    bool finished[2] = {q[0].live, q[1].live};      // pixels whose result this kernel stores (not deferred, not flat)
+    for (int it = 0; it < iters; ++it) {
+        // where each pixel's window lies in the staged second image; leave the loop / defer as needed
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (!q[k].live) continue;
+            if (q[k].ppx < -hw || q[k].ppx >= (float)W || q[k].ppy < -hw || q[k].ppy >= (float)H) { q[k].live = false; continue; }
+            const float fx = floorf(q[k].ppx), fy = floorf(q[k].ppy);
+            q[k].ax = q[k].ppx - fx; q[k].ay = q[k].ppy - fy;
+            const int rx = lk_to_int(fx) - jx0, ry = lk_to_int(fy) - jy0;
+            if (rx < 0 || ry < 0 || rx + LKT_WIN >= LKT_JW || ry + LKT_WIN >= LKT_JH) {        // outside the neighbourhood: deferred
+                q[k].live = false; finished[k] = false;
+                list[atomicAdd(count, 1u)] = (unsigned)((size_t)(gy + k) * W + gx);
+                continue;
+            }
+            q[k].joff = ry * LKT_JP + rx;
+            q[k].b1 = q[k].b2 = 0.f;
+        }
+        if (__builtin_amdgcn_ballot_w64(q[0].live || q[1].live) == 0) break;
+        // lanes with nothing to do walk a harmless window (offset 0) and drop the result
+        const float *j0p = sJ + (q[0].live ? q[0].joff : 0), *j1p = sJ + (q[1].live ? q[1].joff : 0);
+        const float ax0 = q[0].ax, ay0 = q[0].ay, ax1 = q[1].ax, ay1 = q[1].ay;
+        float h0[LKT_WIN], h1[LKT_WIN], b10 = 0.f, b20 = 0.f, b11 = 0.f, b21 = 0.f;
+        {   // row 0 of both windows, interpolated along x
+            float a = j0p[0], b = j1p[0];
+#pragma unroll
+            for (int ox = 0; ox < LKT_WIN; ++ox) {
+                const float an = j0p[ox + 1], bn = j1p[ox + 1];
+                h0[ox] = fmaf(ax0, an - a, a); h1[ox] = fmaf(ax1, bn - b, b);
+                a = an; b = bn;
+            }
+        }
+        // pixel 0 takes sample rows 0..26 of the lane, pixel 1 rows 1..27; both advance one row of J per round
+#define LKT_TAP(K, HP, JP, AX, AY, B1, B2, JOLD)                                                 \
+        {                                                                                        \
+            const float jn = JP[ox + 1];                                                         \
+            const float h = fmaf(AX, jn - JOLD, JOLD);                                           \
+            const float ji = fmaf(AY, h - HP[ox], HP[ox]);                                       \
+            const float df = ji - vi;                                                            \
+            B1 = fmaf(df, dx, B1); B2 = fmaf(df, dy, B2);                                        \
+            HP[ox] = h; JOLD = jn;                                                               \
+        }
+        {   // sample row 0: pixel 0 only
+            j0p += LKT_JP;
+            float a = j0p[0];
+#pragma unroll
+            for (int ox = 0; ox < LKT_WIN; ++ox) {
+                const float vi = pI[ox], dx = pDx[ox], dy = pDy[ox];
+                LKT_TAP(0, h0, j0p, ax0, ay0, b10, b20, a)
+            }
+        }
+#pragma unroll 1
+        for (int sy = 1; sy < LKT_WIN; ++sy) {
+            j0p += LKT_JP; j1p += LKT_JP;
+            float a = j0p[0], b = j1p[0];
+#pragma unroll
+            for (int ox = 0; ox < LKT_WIN; ++ox) {
+                const float vi = pI[sy * LKT_SP + ox], dx = pDx[sy * LKT_SP + ox], dy = pDy[sy * LKT_SP + ox];
+                LKT_TAP(0, h0, j0p, ax0, ay0, b10, b20, a)
+                LKT_TAP(1, h1, j1p, ax1, ay1, b11, b21, b)
+            }
+        }
+        {   // sample row 27: pixel 1 only
+            j1p += LKT_JP;
+            float b = j1p[0];
+#pragma unroll
+            for (int ox = 0; ox < LKT_WIN; ++ox) {
+                const float vi = pI[LKT_WIN * LKT_SP + ox], dx = pDx[LKT_WIN * LKT_SP + ox], dy = pDy[LKT_WIN * LKT_SP + ox];
+                LKT_TAP(1, h1, j1p, ax1, ay1, b11, b21, b)
+            }
+        }
+#undef LKT_TAP
+        q[0].b1 = b10; q[0].b2 = b20; q[1].b1 = b11; q[1].b2 = b21;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (!q[k].live) continue;
+            const float ddx = fmaf(q[k].A12, q[k].b2, -(q[k].A22 * q[k].b1)) * 32.0f;
+            const float ddy = fmaf(q[k].A12, q[k].b1, -(q[k].A11 * q[k].b2)) * 32.0f;
+            q[k].ppx += ddx; q[k].ppy += ddy;
+            if (fabsf(ddx) < 0.01f && fabsf(ddy) < 0.01f) q[k].live = false;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+        if (finished[k]) {
+            const size_t gid = (size_t)(gy + k) * W + gx;
+            Uout[gid] = (q[k].ppx + hw) - (float)gx;
+            Vout[gid] = (q[k].ppy + hw) - (float)(gy + k);
+        }
+}
+
+extern "C" int ofri_lk_set_mode(ofri_ctx *ctx, int mode) {
+    OFRI_REQUIRE(ctx, "null context");
+    OFRI_REQUIRE(mode == 0 || mode == -1, "mode: 0 fast (tile of pixels where the window allows), -1 exact (one wavefront per pixel)");
+    ctx->lk_mode = mode;
+    return OFRI_OK;
+}
+
 extern "C" int ofri_lk_compute(ofri_ctx *ctx, const float *im1, const float *im2, const float *U_in, const float *V_in,
                                float *U_out, float *V_out, int rows, int cols, int niter, int half_window,
                                int asym_left, int asym_right, int asym_top, int asym_bottom) {
@@ -168,6 +412,24 @@ extern "C" int ofri_lk_compute(ofri_ctx *ctx, const float *im1, const float *im2
     p.half_x = p.half_y = (p.win_x - 1) >> 1;
     p.asym_l = asym_left; p.asym_r = asym_right; p.asym_t = asym_top; p.asym_b = asym_bottom;
     p.iters = niter;
+    const bool tile_ok = ctx->lk_mode == 0 && half_window == LKT_HW && !(asym_left | asym_right | asym_top | asym_bottom) &&
+                         U_out != U_in && V_out != V_in && U_out != V_in && V_out != U_in;
+    if (tile_ok) {
+        // fast mode: tiles of pixels; the pixels it defers (displaced window outside the staged neighbourhood) follow
+        const size_t n = (size_t)rows * cols;
+        PoolBuf lst(ctx);
+        OFRI_TRY(lst.get((n + 1) * sizeof(unsigned)));
+        unsigned *count = lst.as<unsigned>(), *list = count + 1;
+        OFRI_HIP(hipMemsetAsync(count, 0, sizeof(unsigned), ctx->stream));
+        const int tiles_x = ceil_div(cols, LKT_PX), tiles = tiles_x * ceil_div(rows, LKT_PY);
+        k_lk_tile<<<tiles, 256, 0, ctx->stream>>>(im1, im2, U_in, V_in, U_out, V_out, rows, cols, niter, tiles_x, list, count);
+        OFRI_LAUNCH_CHECK();
+        int gl = (int)((n + LK_PX - 1) / LK_PX);
+        if (gl > 2048) gl = 2048;
+        k_lk_list<<<gl, 64 * LK_PX, 0, ctx->stream>>>(im1, im2, U_in, V_in, U_out, V_out, rows, cols, p, list, count);
+        OFRI_LAUNCH_CHECK();
+        return OFRI_OK;
+    }
     dim3 g(ceil_div(cols, LK_PX), rows);
     k_lk_dense<<<g, 64 * LK_PX, 0, ctx->stream>>>(im1, im2, U_in, V_in, U_out, V_out, rows, cols, p);
     OFRI_LAUNCH_CHECK();

@@ -741,8 +741,9 @@ def test_farneback_in_driver_and_with_liushen(ctx, pair):
 # ------------------------------------------------------------------------------ dense Lucas-Kanade
 # Parity unpinned by reference outputs (the kernel needs an OpenCL image sampler); compared against the
 # CPU restatement of the kernel text, which uses the same exact float32 bilinear sampling.
-@pytest.mark.parametrize("shape,hw,nit", [((48, 56), 13, 5), ((33, 41), 6, 3), ((40, 40), 15, 2)])
-def test_lk_vs_oracle(ctx, shape, hw, nit):
+@pytest.mark.parametrize("mode", [-1, 0], ids=["exact", "fast"])
+@pytest.mark.parametrize("shape,hw,nit", [((48, 56), 13, 5), ((33, 41), 6, 3), ((40, 40), 15, 2), ((70, 101), 13, 5)])
+def test_lk_vs_oracle(ctx, shape, hw, nit, mode):
     from denseLucasKanade_PyCL import denseLucasKanade_PyCl
     from oracle import lk
     from piv_synth import synth_piv
@@ -752,13 +753,23 @@ def test_lk_vs_oracle(ctx, shape, hw, nit):
     U0 = (0.2 * rng.standard_normal(shape)).astype(np.float32); V0 = (0.2 * rng.standard_normal(shape)).astype(np.float32)
     a[:6, :20] = 0.0                       # a flat corner: singular structure tensor only where the window is empty
     U0[5, 7] = 500.0                       # a start point far outside the image: the loop must bail out
-    U, V, e = denseLucasKanade_PyCl(Niter=nit, halfWindow=hw).compute(a, b, U0.copy(), V0.copy())
+    U0[20:24, 30:33] += 9.0                # displacements far from their neighbours': outside the tile kernel's staged neighbourhood
+    V0[30, 10:14] -= 7.5
+    ctx.set_lk_mode(mode)
+    try:
+        U, V, e = denseLucasKanade_PyCl(Niter=nit, halfWindow=hw).compute(a, b, U0.copy(), V0.copy())
+    finally:
+        ctx.set_lk_mode(0)
     Ur, Vr = lk.lk_dense(a, b, U0, V0, nit, hw)
     assert e is True and U.dtype == np.float32 and U.shape == shape
     bad = (np.abs(U - Ur) > 1e-4) | (np.abs(V - Vr) > 1e-4)
-    r = flow_rel(U, V, Ur, Vr)
-    print("lk", shape, hw, nit, "rel L2 vs oracle", r, "pixels off by >1e-4:", int(bad.sum()))
-    assert r < 1e-5 and bad.mean() < 1e-3
+    sane = np.abs(Ur) < 100                # the bailed-out pixel keeps its 500 px and would swamp the norm
+    r = flow_rel(U[sane], V[sane], Ur[sane], Vr[sane])
+    print("lk", shape, hw, nit, "mode", mode, "rel L2 vs oracle", r, "pixels off by >1e-4:", int(bad.sum()), "largest", float(np.abs(U - Ur).max()))
+    # exact mode: the oracle's arithmetic (a Newton loop's stopping test can still flip on a rounding difference);
+    # fast mode: sums in another order, factored interpolation
+    assert r < (1e-5 if mode == -1 else 1e-4) and bad.mean() < (1e-3 if mode == -1 else 1e-2)
+    assert float(np.abs(U - Ur)[sane].max()) < 2e-3 and float(np.abs(V - Vr).max()) < 2e-3
 
 
 def test_lk_asymmetric_windows_and_driver(ctx, pair):
