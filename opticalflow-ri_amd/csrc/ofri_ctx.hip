@@ -144,8 +144,12 @@ extern "C" int ofri_free(ofri_ctx *ctx, void *dptr) {
     OFRI_REQUIRE(it != ctx->live.end(), "pointer %p was not allocated by this context", dptr);
     // stream-ordered reuse: every consumer of the pool enqueues on ctx->stream, so a block handed
     // out again is only touched after the work that last used it
+    auto gh = ctx->graph_held.find(dptr);
     if (ctx->capturing && ctx->cap_blocks.count(dptr)) ctx->cap_pool[it->second].push_back(dptr);
-    else ctx->pool[it->second].push_back(dptr);
+    else if (gh != ctx->graph_held.end()) {           // a captured graph still writes this block: it stays the graph's
+        gh->second->blocks.push_back({dptr, it->second});
+        ctx->graph_held.erase(gh);
+    } else ctx->pool[it->second].push_back(dptr);
     ctx->live.erase(it);
     return OFRI_OK;
 }
@@ -175,6 +179,9 @@ extern "C" int ofri_graph_end(ofri_ctx *ctx, ofri_graph **out) {
     for (auto &kv : ctx->cap_pool)
         for (void *p : kv.second) owned.push_back({p, kv.first});
     ctx->cap_pool.clear();
+    std::vector<void *> held;                            // handed out during the capture and not freed yet
+    for (auto &kv : ctx->cap_blocks)
+        if (ctx->live.count(kv.first)) held.push_back(kv.first);
     ctx->cap_blocks.clear();
     hipGraphExec_t exec = nullptr;
     hipError_t e2 = hipSuccess;
@@ -188,6 +195,7 @@ extern "C" int ofri_graph_end(ofri_ctx *ctx, ofri_graph **out) {
     }
     ofri_graph *gr = new ofri_graph();
     gr->ctx = ctx; gr->graph = g; gr->exec = exec; gr->blocks = std::move(owned);
+    for (void *p : held) ctx->graph_held[p] = gr;
     *out = gr;
     return OFRI_OK;
 }
@@ -206,6 +214,8 @@ extern "C" int ofri_graph_destroy(ofri_graph *graph) {
     (void)hipGraphExecDestroy(graph->exec);
     (void)hipGraphDestroy(graph->graph);
     for (auto &b : graph->blocks) graph->ctx->pool[b.second].push_back(b.first);
+    for (auto it = graph->ctx->graph_held.begin(); it != graph->ctx->graph_held.end();)      // what the caller still holds is plain memory again
+        it = it->second == graph ? graph->ctx->graph_held.erase(it) : std::next(it);
     delete graph;
     return OFRI_OK;
 }

@@ -34,6 +34,9 @@ struct ofri_ctx {
     bool capturing = false;
     std::map<size_t, std::vector<void *>> cap_pool;    // blocks freed again during the capture
     std::map<void *, size_t> cap_blocks;               // every block handed out during the capture
+    // blocks handed out during a finished capture that the caller still holds (a plan's result arrays): the graph's
+    // kernels write them on every replay, so when freed they join that graph's scratch memory, not the pool
+    std::map<void *, struct ofri_graph *> graph_held;
 };
 
 struct ofri_graph {

@@ -217,25 +217,33 @@ __device__ __forceinline__ double ls_total_error(double ta, double tb, double in
 // 64 and at most 256 threads) inside launch k; its wavefronts sum different sweeps side by side.
 struct LsPrev { const double *partials; int nparts, T, src, dst; };
 __device__ void ls_check(const LsPrev &pv, double inv_rc, double tol, LsState *state, int k) {
-    __shared__ double sums[8][2];
+    __shared__ double sums[8][4][2];        // [sweep][slice][u | v]
     const int tid = threadIdx.y * blockDim.x + threadIdx.x, nthr = blockDim.x * blockDim.y, nw = nthr >> 6, w = tid >> 6, ln = tid & 63;
     if (state->done[(k + 1) & 1]) {            // met before: hand the flag on
         if (tid == 0) state->done[k & 1] = 1;
         return;
     }
-    for (int j = w; j < pv.T; j += nw) {
-        double a = 0.0, b = 0.0;
+    // G wavefronts share a sweep's partial sums (all of them when the block is one sweep: a launch is not over before
+    // its check is, and a field of 4096 x 4096 pixels has 32768 partial sums per sweep)
+    const int G = nw >= pv.T ? nw / pv.T : 1, slice = w % G;
+    for (int j = w / G; j < pv.T; j += nw / G) {
+        double a = 0.0, b = 0.0, a2 = 0.0, b2 = 0.0;
         const double *pa = pv.partials + (size_t)(2 * j) * pv.nparts, *pb = pa + pv.nparts;
-        for (int i = ln; i < pv.nparts; i += 64) { a += pa[i]; b += pb[i]; }
-        a = ls_wave_sum(a);
-        b = ls_wave_sum(b);
-        if (ln == 0) { sums[j][0] = a; sums[j][1] = b; }
+        int i = slice * 64 + ln;
+        for (; i + 64 * G < pv.nparts; i += 128 * G) { a += pa[i]; b += pb[i]; a2 += pa[i + 64 * G]; b2 += pb[i + 64 * G]; }
+        if (i < pv.nparts) { a += pa[i]; b += pb[i]; }
+        a = ls_wave_sum(a + a2);
+        b = ls_wave_sum(b + b2);
+        if (ln == 0) { sums[j][slice][0] = a; sums[j][slice][1] = b; }
     }
     __syncthreads();
     if (tid == 0) {
         int stop = 0;
+        const int Gs = nw >= pv.T ? nw / pv.T : 1;
         for (int j = 0; j < pv.T && !stop; ++j) {
-            const double err = ls_total_error(sums[j][0], sums[j][1], inv_rc);
+            double ta = 0.0, tb = 0.0;
+            for (int g = 0; g < Gs; ++g) { ta += sums[j][g][0]; tb += sums[j][g][1]; }
+            const double err = ls_total_error(ta, tb, inv_rc);
             state->err = err;
             state->iters += 1;
             if (!(err > tol)) {

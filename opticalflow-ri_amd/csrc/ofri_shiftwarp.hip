@@ -62,6 +62,8 @@ extern "C" int ofri_warp_shift_ofe(ofri_ctx *ctx, const float *im, const float *
     OFRI_REQUIRE(im && U && V && out, "null pointer");
     OFRI_REQUIRE(rows > 0 && cols > 0 && (long long)rows * cols < (1LL << 31), "bad shape %d x %d", rows, cols);
     OFRI_REQUIRE(taps_host && ntaps >= 1 && (ntaps & 1), "taps: odd count expected, got %d", ntaps);
+    // this call reads the range check back: refuse a capture before anything is enqueued into it
+    OFRI_REQUIRE(!ctx->capturing, "ofri_warp_shift_ofe waits for the GPU (its range check), which a captured sequence cannot do");
     const int H = rows, W = cols, n = rows * cols;
     const size_t bytes = (size_t)n * sizeof(float);
     PoolBuf win(ctx), dU(ctx), dV(ctx), shifted(ctx), oob(ctx);

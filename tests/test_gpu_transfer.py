@@ -223,3 +223,35 @@ def test_stream_flows_overlaps_copies_and_keeps_bits(pair):
     assert len(got) == len(want)
     for (U, V), (Ur, Vr) in zip(got, want):
         assert U.tobytes() == Ur.tobytes() and V.tobytes() == Vr.tobytes()
+
+
+def test_blocks_a_captured_graph_writes_never_reach_the_pool_while_it_lives():
+    """A block handed out during a capture and still held at ofri_graph_end is written by every replay: freeing it
+    later must not hand it to anybody else before the graph is destroyed."""
+    import ctypes as C
+    import _ofri
+    lib = _ofri.lib()
+    ctx = _ofri.Context(0)
+    try:
+        n = 3 << 20
+        src = ctx.upload(np.full(n // 4, 7.0, np.float32))
+        warm = ctx.empty((n // 4,)); del warm                   # one block of that size in the pool
+        ctx.graph_begin()
+        held = ctx.empty((n // 4,))                             # handed out during the capture, kept past its end
+        _ofri.check(lib.ofri_copy(ctx.handle, held.ptr, src.ptr, n))
+        g = ctx.graph_end()
+        p_held = held.ptr
+        del held                                                # freed while the graph lives
+        other = [ctx.empty((n // 4,)) for _ in range(3)]
+        assert all(o.ptr != p_held for o in other)
+        for o in other:
+            _ofri.check(lib.ofri_zero(ctx.handle, o.ptr, n))
+        g.launch()                                              # writes the held block: must not land in `other`
+        ctx.sync()
+        assert all(float(o.numpy().max()) == 0.0 for o in other)
+        del other
+        g.close()                                               # now the block is ordinary pool memory again
+        again = [ctx.empty((n // 4,)) for _ in range(5)]
+        assert any(a.ptr == p_held for a in again)
+    finally:
+        ctx.close()
