@@ -119,7 +119,8 @@ int ofri_hs_derivs(ofri_ctx *ctx, const float *first, const float *second,
  *   t = 0   automatic: row-streaming pipeline (12 sweeps per launch) on fields of 2048 x 2048 pixels and
  *           more, tile kernel (up to 8 per launch) for the rest and for smaller fields;
  *   t = 1   one launch per sweep;  t = 2..8  tile kernel with at most t sweeps per launch;
- *   t = 16  row-streaming pipeline for every sweep, any field size;
+ *   t = 16  row-streaming pipeline (strips of 128 columns) for every sweep, any field size;
+ *   t = 32  the same with strips of 256 columns (what t = 0 picks where the row chunks stay long: 4096 x 4096);
  *   t = -1  exact mode: one launch per sweep with scipy's float64 tap accumulation and NumPy's unfused
  *           float32 element operations, bit-identical to the reference.
  * All settings but -1 give the same bits as each other. */

@@ -196,7 +196,7 @@ static int hs_stream_share(ofri_ctx *ctx, const void *const *ptrs, int nptrs, in
     size_t bits = 0;
     for (int i = 0; i < nptrs; ++i) bits |= (size_t)ptrs[i];
     if ((bits & 15) != 0 || (cols & 3) != 0 || cols < 8 || niter <= 0) return 0;
-    if (ctx->hs_fuse == 16) return niter;
+    if (ctx->hs_fuse == 16 || ctx->hs_fuse == 32) return niter;
     const int per = ofri_hs_stream_sweeps();
     if (ctx->hs_fuse == 0 && ofri_hs_stream_pays(rows, cols) && niter >= 2 * per) {
         // up to 4 left-over sweeps ride in a deeper last launch (hs_stream_path); more of them go to the tile kernel

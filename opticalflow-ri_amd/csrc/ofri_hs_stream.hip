@@ -19,20 +19,24 @@
 #include "ofri_hs_math.h"
 #include "ofri_hs_stream.h"
 
-#define SL_RX 128                        // strip width (32 lanes x 4 pixels)
 #define SL_PF 6                          // rows the loader keeps in flight
 // The depth is a template parameter.  Built: NL = 12 sweeps per launch (three stage wavefronts + loader, 40 KB of LDS,
 // four workgroups per CU) for the bulk, and NL = 16 (four stage wavefronts + loader, 52 KB, three workgroups per CU) for
 // a tail of 13 to 16 sweeps: 263 us per launch at 4096 x 4096 against 165 us for 12 sweeps, so 16.4 against 13.7 us per
 // sweep, but cheaper than a launch of 12 and a launch for the rest (with four coefficient planes and two workgroups per
 // CU it took 327 us).
-template <int NL> struct SlCfg {
-    static constexpr int NS = NL / 2;                // pipeline stages (half-wavefronts)
-    static constexpr int OX = SL_RX - 2 * NL;        // stored width: the sweeps eat NL columns on each side
+// LN: lanes of a stage, 32 (a stage is half a wavefront, strips of 128 columns) or 64 (a whole wavefront, strips of 256
+// columns: the sweeps' lost columns are 24 of 256 instead of 24 of 128, at twice the LDS per workgroup; pays where the
+// row chunks stay long with two workgroups per CU, i.e. on 4096 x 4096 fields).
+template <int NL, int LN = 32> struct SlCfg {
+    static constexpr int NS = NL / 2;                // pipeline stages
+    static constexpr int RX = 4 * LN;                // strip width
+    static constexpr int OX = RX - 2 * NL;           // stored width: the sweeps eat NL columns on each side
     static constexpr int LAG = 3 * NS;               // the last stage's second sweep runs this many rows behind the loader
     static constexpr int CR = LAG;                   // coefficient ring rows: rows rho-(LAG-1) .. rho are live
-    static constexpr int THREADS = NS * 32 + 64;
-    static constexpr int PER_CU = NL == 12 ? 4 : 3;  // workgroups per CU that the LDS (40 KB each at NL = 12, 52 KB at 16) and 128 registers allow
+    static constexpr int THREADS = NS * LN + 2 * LN;     // + the loader: two sets of LN lanes (U, A, C and V, B)
+    // workgroups per CU that the LDS (LN = 32: 40 KB each at NL = 12, 52 KB at 16) and 128 registers allow
+    static constexpr int PER_CU = LN == 64 ? (NL == 12 ? 2 : 1) : (NL == 12 ? 4 : 3);
     static constexpr int MIN_CHUNK = 128;            // chunk rows below which one workgroup per CU fewer is launched
 };
 #define SL_NL_MAIN 12
@@ -94,12 +98,12 @@ struct SlStage {                 // registers of one pipeline stage (one lane)
 
 // one step of a stage: first sweep at row rA, second sweep at row rA-1.  ACC: the last stage adds its row to what the
 // destination holds; those values are fetched two steps (rows) ahead (row2: the row two below rowU, rowV is stored later).
-template <int NL, bool FULL, bool ACC>
-__device__ __forceinline__ void sl_stage_step(SlStage &st, float4 (&ring)[SlCfg<NL>::NS][2][2][32],
-                                              float4 (&coef)[SlCfg<NL>::CR][3][32], int stage, int l, bool passA, bool passB,
+template <int NL, int LN, bool FULL, bool ACC>
+__device__ __forceinline__ void sl_stage_step(SlStage &st, float4 (&ring)[SlCfg<NL, LN>::NS][2][2][LN],
+                                              float4 (&coef)[SlCfg<NL, LN>::CR][3][LN], int stage, int l, bool passA, bool passB,
                                               bool store_lane, int lane_off, float *__restrict__ rowU, float *__restrict__ rowV,
                                               bool row_ok, long long row2, bool row2_ok) {
-    constexpr int SL_NS = SlCfg<NL>::NS, SL_CR = SlCfg<NL>::CR;
+    constexpr int SL_NS = SlCfg<NL, LN>::NS, SL_CR = SlCfg<NL, LN>::CR;
     // newest input row rA+1, written one step ago
     const float4 nu4 = ring[stage][(st.rA + 1) & 1][0][l], nv4 = ring[stage][(st.rA + 1) & 1][1][l];
     SlCoef g;
@@ -155,20 +159,20 @@ __device__ __forceinline__ float4 sl_load4(const float *__restrict__ row, const 
     return make_float4(row[c.x0], row[c.x1], row[c.x2], row[c.x3]);
 }
 
-// The loader wavefront's loop.  Lanes 0-31 carry U, A, C; lanes 32-63 carry V, B (each one plane
-// after its partner, so the row address is a scalar base plus a per-lane offset).  Rows outside the image are
-// the reflected rows.  EDGE: the strip reaches over the left or right edge of the image.  ZERO: the flow is
-// zero on input and is not read.
-template <int NL, bool EDGE, bool ZERO>
-__device__ __forceinline__ void sl_loader(const SlPlanes &in, float4 (&ring)[SlCfg<NL>::NS][2][2][32],
-                                          float4 (&coef)[SlCfg<NL>::CR][3][32], int tid, int x0, int rho0, int NS, int H, int W) {
-    constexpr int SL_CR = SlCfg<NL>::CR;
-    const int lj = tid & 31, lset = (tid >> 5) & 1;
+// The loader's loop: two sets of LN lanes (two half-wavefronts, or two wavefronts for the wide strips).  Set 0 carries
+// U, A, C; set 1 carries V, B (each one plane after its partner, so the row address is a scalar base plus a per-lane
+// offset).  Rows outside the image are the reflected rows.  EDGE: the strip reaches over the left or right edge of
+// the image.  ZERO: the flow is zero on input and is not read.
+template <int NL, int LN, bool EDGE, bool ZERO>
+__device__ __forceinline__ void sl_loader(const SlPlanes &in, float4 (&ring)[SlCfg<NL, LN>::NS][2][2][LN],
+                                          float4 (&coef)[SlCfg<NL, LN>::CR][3][LN], int ltid, int x0, int rho0, int NS, int H, int W) {
+    constexpr int SL_CR = SlCfg<NL, LN>::CR;
+    const int lj = ltid % LN, lset = ltid / LN;                        // ltid: thread index within the loader
     const int lx = x0 + 4 * lj;
     SlCols cols;                                                       // column reflection does not depend on the row
     cols.x = lx; cols.inside = lx >= 0 && lx + 3 < W;
     cols.x0 = sl_refl(lx, W); cols.x1 = sl_refl(lx + 1, W); cols.x2 = sl_refl(lx + 2, W); cols.x3 = sl_refl(lx + 3, W);
-    const long long pl = lset ? (long long)(in.V - in.U) : 0;          // plane stride for the second half-wavefront
+    const long long pl = lset ? (long long)(in.V - in.U) : 0;          // plane stride for the second set
     int lslot = (rho0 + 64 * SL_CR) % SL_CR;                           // slot of the row written next
     // rows in flight: named registers (an array here ends up in scratch memory, which serialises the prefetch)
 #define SL_LOAD(U_, ROW_)                                                                          \
@@ -204,13 +208,14 @@ __device__ __forceinline__ void sl_loader(const SlPlanes &in, float4 (&ring)[SlC
 // FULL: all NL sweeps are wanted (no copy-through selects in the inner loop).  ACC: the result is added to what
 // (Uo, Vo) hold.  All planes are dense with W columns (W % 4 == 0, 16-byte aligned); zero_in: the input flow is
 // zero and in.U, in.V are not read.
-template <int NL, bool FULL, bool ACC>
-__global__ void __launch_bounds__(SlCfg<NL>::THREADS)
+template <int NL, bool FULL, bool ACC, int LN = 32>
+__global__ void __launch_bounds__((SlCfg<NL, LN>::THREADS), (LN == 64 ? 2 : 1))
 k_hs_stream(SlPlanes in, float *__restrict__ Uo, float *__restrict__ Vo, int H, int W, int T, int tiles_x, int chunk_rows,
             int zero_in) {
-    constexpr int SL_NS = SlCfg<NL>::NS, SL_CR = SlCfg<NL>::CR, SL_LAG = SlCfg<NL>::LAG, SL_OX = SlCfg<NL>::OX, SL_NL = NL;
-    __shared__ float4 ring[SL_NS][2][2][32];      // ring[s]: input rows of stage s.  [row & 1][U|V][lane]
-    __shared__ float4 coef[SL_CR][3][32];         // [row slot][A|B|C][lane]
+    constexpr int SL_NS = SlCfg<NL, LN>::NS, SL_CR = SlCfg<NL, LN>::CR, SL_LAG = SlCfg<NL, LN>::LAG, SL_OX = SlCfg<NL, LN>::OX, SL_NL = NL;
+    constexpr int SL_RX = SlCfg<NL, LN>::RX;
+    __shared__ float4 ring[SL_NS][2][2][LN];      // ring[s]: input rows of stage s.  [row & 1][U|V][lane]
+    __shared__ float4 coef[SL_CR][3][LN];         // [row slot][A|B|C][lane]
     const int tid = threadIdx.x;
     // Workgroups go to the 8 XCDs round-robin by index, and each XCD has its own L2.  Renumber them so that an
     // XCD gets a run of neighbouring strips and chunks: the columns and fill rows that neighbours share are then
@@ -228,18 +233,18 @@ k_hs_stream(SlPlanes in, float *__restrict__ Uo, float *__restrict__ Vo, int H, 
 
     // The loader and the stages run separate loops (their registers then overlap instead of adding up);
     // both execute one barrier per step, NS in all.
-    if (tid >= SL_NS * 32) {
+    if (tid >= SL_NS * LN) {
         const bool edge = x0 < 0 || x0 + SL_RX > W;
         if (edge) {
-            if (zero_in) sl_loader<NL, true, true>(in, ring, coef, tid, x0, rho0, NS, H, W);
-            else sl_loader<NL, true, false>(in, ring, coef, tid, x0, rho0, NS, H, W);
+            if (zero_in) sl_loader<NL, LN, true, true>(in, ring, coef, tid - SL_NS * LN, x0, rho0, NS, H, W);
+            else sl_loader<NL, LN, true, false>(in, ring, coef, tid - SL_NS * LN, x0, rho0, NS, H, W);
         } else {
-            if (zero_in) sl_loader<NL, false, true>(in, ring, coef, tid, x0, rho0, NS, H, W);
-            else sl_loader<NL, false, false>(in, ring, coef, tid, x0, rho0, NS, H, W);
+            if (zero_in) sl_loader<NL, LN, false, true>(in, ring, coef, tid - SL_NS * LN, x0, rho0, NS, H, W);
+            else sl_loader<NL, LN, false, false>(in, ring, coef, tid - SL_NS * LN, x0, rho0, NS, H, W);
         }
     } else {
         // ---- stage half-wavefronts ---------------------------------------------------------------------
-        const int stage = tid >> 5, l = tid & 31;
+        const int stage = tid / LN, l = tid % LN;
         SlStage st;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -251,13 +256,13 @@ k_hs_stream(SlPlanes in, float *__restrict__ Uo, float *__restrict__ Vo, int H, 
         st.rA = rho0 - 2 - 3 * stage;
         st.cslot = (st.rA + 64 * SL_CR) % SL_CR;
         const bool passA = 2 * stage >= T, passB = 2 * stage + 1 >= T;    // fewer than NL sweeps asked: copy rows through
-        const bool store_lane = l >= SL_NL / 4 && l < 32 - SL_NL / 4 && (x0 + 4 * l) < W;
+        const bool store_lane = l >= SL_NL / 4 && l < LN - SL_NL / 4 && (x0 + 4 * l) < W;
         const int lane_off = x0 + 4 * l;
         // six steps per round (NS is a multiple): the row registers rotate by renaming instead of moves
 #define SL_STEP(U_)                                                                                                   \
     {                                                                                                                 \
         const int ro = rho0 - SL_LAG + t + (U_);          /* row the last stage finishes at this step */              \
-        sl_stage_step<NL, FULL, ACC>(st, ring, coef, stage, l, passA, passB, store_lane, lane_off, Uo + (long long)ro * W, \
+        sl_stage_step<NL, LN, FULL, ACC>(st, ring, coef, stage, l, passA, passB, store_lane, lane_off, Uo + (long long)ro * W, \
                                      Vo + (long long)ro * W, ro >= ya && ro < yb, 2LL * W, ro + 2 >= ya && ro + 2 < yb); \
         __syncthreads();                                                                                              \
     }
@@ -316,25 +321,34 @@ int ofri_hs_scaled_coefs(ofri_ctx *ctx, const float *fx, const float *fy, const 
     OFRI_LAUNCH_CHECK();
     return OFRI_OK;
 }
-template <int NL>
+template <int NL, int LN>
 static void sl_launch(ofri_ctx *ctx, const SlPlanes &in, float *uo, float *vo, int H, int W, int T, int zero_in, bool acc) {
-    const int tiles_x = ceil_div(W, SlCfg<NL>::OX);
+    using Cfg = SlCfg<NL, LN>;
+    const int tiles_x = ceil_div(W, Cfg::OX);
     // As many row chunks as fill the chip once with the workgroups per CU that the LDS allows.  Every chunk pays
     // NL + LAG rows of fill, so the last workgroup per CU is used only where the chunks stay long (4096 x 4096:
     // 161 against 170 us per launch; 2048 x 2048: 71 against 66 us with it).
-    int nchunks = SlCfg<NL>::PER_CU * ofri_ctx_ncu(ctx) / tiles_x;
+    int nchunks = Cfg::PER_CU * ofri_ctx_ncu(ctx) / tiles_x;
     if (nchunks < 1) nchunks = 1;
-    if (ceil_div(H, nchunks) < SlCfg<NL>::MIN_CHUNK && SlCfg<NL>::PER_CU > 2) nchunks = max(1, (SlCfg<NL>::PER_CU - 1) * ofri_ctx_ncu(ctx) / tiles_x);
+    if (ceil_div(H, nchunks) < Cfg::MIN_CHUNK && Cfg::PER_CU > 2) nchunks = max(1, (Cfg::PER_CU - 1) * ofri_ctx_ncu(ctx) / tiles_x);
     const int chunk_rows = ceil_div(H, nchunks);
     nchunks = ceil_div(H, chunk_rows);
-    const int grid = tiles_x * nchunks, thr = SlCfg<NL>::THREADS;
+    const int grid = tiles_x * nchunks, thr = Cfg::THREADS;
     if (T == NL) {
-        if (acc) k_hs_stream<NL, true, true><<<grid, thr, 0, ctx->stream>>>(in, uo, vo, H, W, T, tiles_x, chunk_rows, zero_in);
-        else k_hs_stream<NL, true, false><<<grid, thr, 0, ctx->stream>>>(in, uo, vo, H, W, T, tiles_x, chunk_rows, zero_in);
+        if (acc) k_hs_stream<NL, true, true, LN><<<grid, thr, 0, ctx->stream>>>(in, uo, vo, H, W, T, tiles_x, chunk_rows, zero_in);
+        else k_hs_stream<NL, true, false, LN><<<grid, thr, 0, ctx->stream>>>(in, uo, vo, H, W, T, tiles_x, chunk_rows, zero_in);
     } else {
-        if (acc) k_hs_stream<NL, false, true><<<grid, thr, 0, ctx->stream>>>(in, uo, vo, H, W, T, tiles_x, chunk_rows, zero_in);
-        else k_hs_stream<NL, false, false><<<grid, thr, 0, ctx->stream>>>(in, uo, vo, H, W, T, tiles_x, chunk_rows, zero_in);
+        if (acc) k_hs_stream<NL, false, true, LN><<<grid, thr, 0, ctx->stream>>>(in, uo, vo, H, W, T, tiles_x, chunk_rows, zero_in);
+        else k_hs_stream<NL, false, false, LN><<<grid, thr, 0, ctx->stream>>>(in, uo, vo, H, W, T, tiles_x, chunk_rows, zero_in);
     }
+}
+// strips of 256 columns where two workgroups per CU still get long row chunks
+static bool sl_wide_pays(ofri_ctx *ctx, int H, int W) {
+    if (ctx->hs_fuse == 32) return true;                    // asked for (ofri_hs_set_fuse)
+    if (ctx->hs_fuse == 16) return false;
+    const int tiles_x = ceil_div(W, SlCfg<SL_NL_MAIN, 64>::OX);
+    const int nchunks = max(1, SlCfg<SL_NL_MAIN, 64>::PER_CU * ofri_ctx_ncu(ctx) / tiles_x);
+    return ceil_div(H, nchunks) >= 128;
 }
 
 // n sweeps starting from the pair *cur of the set (the last launch shorter if n is not a multiple of 12).
@@ -357,8 +371,9 @@ int ofri_sl_sweeps(ofri_ctx *ctx, OfriSlSet &s, int n, bool to_dense, bool accum
         const bool dense = remaining == T && to_dense;
         SlPlanes in{s.U[c], s.V[c], s.fx, s.fy, s.ft};
         float *uo = dense ? Uout : s.U[c ^ 1], *vo = dense ? Vout : s.V[c ^ 1];
-        if (deep) sl_launch<SL_NL_DEEP>(ctx, in, uo, vo, H, W, T, s.zero_in, dense && accumulate);
-        else sl_launch<SL_NL_MAIN>(ctx, in, uo, vo, H, W, T, s.zero_in, dense && accumulate);
+        if (deep) sl_launch<SL_NL_DEEP, 32>(ctx, in, uo, vo, H, W, T, s.zero_in, dense && accumulate);
+        else if (sl_wide_pays(ctx, H, W)) sl_launch<SL_NL_MAIN, 64>(ctx, in, uo, vo, H, W, T, s.zero_in, dense && accumulate);
+        else sl_launch<SL_NL_MAIN, 32>(ctx, in, uo, vo, H, W, T, s.zero_in, dense && accumulate);
         OFRI_LAUNCH_CHECK();
         s.zero_in = 0;
         if (!dense) c ^= 1;

@@ -170,7 +170,7 @@ def test_hs_launch_shapes_agree_bitwise(ctx, shape, nit):
     rng = np.random.default_rng(shape[0] * 7 + shape[1] + nit)
     host = [rng.standard_normal(shape).astype(np.float32) for _ in range(5)]
     out = {}
-    for fuse in (1, 8, 16):
+    for fuse in (1, 8, 16, 32):                  # 16 / 32: the pipeline with strips of 128 / 256 columns
         ctx.set_hs_fuse(fuse)
         try:
             d = [ctx.upload(x) for x in host]
@@ -178,7 +178,7 @@ def test_hs_launch_shapes_agree_bitwise(ctx, shape, nit):
             out[fuse] = (d[0].numpy(), d[1].numpy())
         finally:
             ctx.set_hs_fuse(0)
-    for fuse in (8, 16):
+    for fuse in (8, 16, 32):
         np.testing.assert_array_equal(out[fuse][0], out[1][0]); np.testing.assert_array_equal(out[fuse][1], out[1][1])
 
 
