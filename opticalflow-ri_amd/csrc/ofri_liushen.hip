@@ -619,7 +619,7 @@ static void lt_grid(ofri_ctx *ctx, int H, int W, int *tiles_x, int *chunk_rows, 
     int nchunks = LtCfg<NL, PX>::PER_CU * ofri_ctx_ncu(ctx) / *tiles_x;
     if (nchunks < 1) nchunks = 1;
     int cr = ceil_div(H, nchunks);
-    if (cr < 16) cr = H < 16 ? H : 16;
+    if (cr < 16) cr = H < 16 ? H : 16;          // shorter chunks are mostly fill; longer ones leave CUs idle (24 to 64 rows measured no better)
     *chunk_rows = cr;
     *tiles = *tiles_x * ceil_div(H, cr);
 }

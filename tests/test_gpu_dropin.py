@@ -45,12 +45,22 @@ def test_example_scripts_call_sequence(tmp_path, pair):
     [U, V] = genericPyramidalOpticalFlow(Iold, Inew, 3.4, HSOpticalFlowAlgoAdapter([21, 45], 100), 2, 1, 0.48,
                                          LiuShenOpticalFlowAlgoAdapter(5))
     assert rel_l2(np.stack([U[::2, ::2], V[::2, ::2]]), np.stack([d["hs_L2_ls_U"], d["hs_L2_ls_V"]])) < 1e-4
-    # Farneback_Fs0_0_PyrLvls2.py and denseLK_Fs2_0_PyrLvls2.py: the Poiseuille profile of the bundled pair
+    # Farneback_Fs0_0_PyrLvls2.py: against the oracle's run of the same call (the reference's OpenCL kernels cannot run
+    # where the fixtures are made: parity unpinned by reference outputs), and the Poiseuille profile of the bundled pair
+    from oracle import farneback as ofb, liushen as ols, lk as olk, pyramid as opyr
     [U, V] = genericPyramidalOpticalFlow(Iold, Inew, 0.0, Farneback_PyCL(platformID=0), 2, 1, None)
+    Ur, Vr = opyr.pyramidal_flow(Iold.copy(), Inew.copy(), 0.0, ofb.FarnebackAdapter(), 2, 1, None)
+    assert rel_l2(np.stack([U, V]), np.stack([Ur, Vr])) < 1e-4
     rows = U[:, 96:416].mean(axis=1)
     assert rows[256] < -3.0 and abs(rows[8]) < 1.5 and abs(V[64:448, 96:416].mean()) < 0.2
+    # denseLK_Fs2_0_PyrLvls2.py (dense LK refined by Liu-Shen(10), no warping) on a crop the oracle can hold in memory
     lkAdapter = denseLucasKanade_PyCl(platformID=0, deviceID=0, Niter=5, halfWindow=13)
-    [U, V] = genericPyramidalOpticalFlow(Iold[128:384, 128:384].copy(), Inew[128:384, 128:384].copy(), 2.0, lkAdapter, 2, 1,
+    c0, c1 = Iold[192:320, 192:320].copy(), Inew[192:320, 192:320].copy()
+    [U, V] = genericPyramidalOpticalFlow(c0.copy(), c1.copy(), 2.0, lkAdapter, 2, 1, 0.48, LiuShenOpticalFlowAlgoAdapter(10), warping=False)
+    Ur, Vr = opyr.pyramidal_flow(c0.copy(), c1.copy(), 2.0, olk.DenseLKAdapter(5, 13), 2, 1, 0.48, ols.LiuShenAdapter(10), warping=False)
+    assert U.shape == (128, 128) and rel_l2(np.stack([U, V]), np.stack([Ur, Vr])) < 1e-4
+    [U, V] = genericPyramidalOpticalFlow(Iold[128:384, 128:384].copy(), Inew[128:384, 128:384].copy(), 2.0,
+                                         denseLucasKanade_PyCl(platformID=0, deviceID=0, Niter=5, halfWindow=13), 2, 1,
                                          0.48, LiuShenOpticalFlowAlgoAdapter(10), warping=False)
     assert U.shape == (256, 256) and np.isfinite(U).all() and U[100:156, 60:196].mean() < -1.0
 
