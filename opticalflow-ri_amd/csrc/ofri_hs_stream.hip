@@ -18,6 +18,7 @@
 #include "ofri_internal.h"
 #include "ofri_hs_math.h"
 #include "ofri_hs_stream.h"
+#include "ofri_prio.h"
 
 #define SL_PF 6                          // rows the loader keeps in flight
 // The depth is a template parameter.  Built: NL = 12 sweeps per launch (three stage wavefronts + loader, 40 KB of LDS,
@@ -57,6 +58,19 @@ __device__ __forceinline__ int sl_refl(int i, int n) {
     return i < n ? i : p - i;
 }
 
+#ifdef OFRI_SL_TRACE
+// measurement build only (tools/hs_wg_trace.py): start, end and placement of every workgroup of the last launch
+#define SL_TRACE_MAX 4096
+__device__ unsigned long long g_sl_trace[SL_TRACE_MAX * 3];
+extern "C" int ofri_debug_sl_trace(unsigned long long *host, int n) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_sl_trace), sizeof(unsigned long long) * 3 * (n < SL_TRACE_MAX ? n : SL_TRACE_MAX)) == hipSuccess ? 0 : 1;
+}
+extern "C" int ofri_debug_sl_trace_clear(void) {
+    void *p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_sl_trace)) != hipSuccess) return 1;
+    return hipMemset(p, 0, sizeof(unsigned long long) * 3 * SL_TRACE_MAX) == hipSuccess ? 0 : 1;
+}
+#endif
 struct SlPlanes { const float *U, *V, *fx, *fy, *ft; };        // dense planes (fx, fy, ft: scaled A, B, C); V, fy one plane after U, fx
 struct SlRow { float u[4], v[4]; };                            // a lane's four pixels of one row
 struct SlCoef { float4 fx, fy, ft; };
@@ -165,7 +179,8 @@ __device__ __forceinline__ float4 sl_load4(const float *__restrict__ row, const 
 // the image.  ZERO: the flow is zero on input and is not read.
 template <int NL, int LN, bool EDGE, bool ZERO>
 __device__ __forceinline__ void sl_loader(const SlPlanes &in, float4 (&ring)[SlCfg<NL, LN>::NS][2][2][LN],
-                                          float4 (&coef)[SlCfg<NL, LN>::CR][3][LN], int ltid, int x0, int rho0, int NS, int H, int W) {
+                                          float4 (&coef)[SlCfg<NL, LN>::CR][3][LN], int ltid, int x0, int rho0, int NS, int H, int W,
+                                          const OfriPrio &pr) {
     constexpr int SL_CR = SlCfg<NL, LN>::CR;
     const int lj = ltid % LN, lset = ltid / LN;                        // ltid: thread index within the loader
     const int lx = x0 + 4 * lj;
@@ -198,7 +213,9 @@ __device__ __forceinline__ void sl_loader(const SlPlanes &in, float4 (&ring)[SlC
         SL_LOAD(U_, rho + SL_PF)                                                   \
         __syncthreads();                                                           \
     }
+    OfriPrioState ps = ofri_prio_begin(pr, NS, blockIdx.x);
     for (int t0 = 0; t0 < NS; t0 += SL_PF) {
+        ofri_prio_turn(t0, pr, ps);
         SL_STEP(0) SL_STEP(1) SL_STEP(2) SL_STEP(3) SL_STEP(4) SL_STEP(5)
     }
 #undef SL_STEP
@@ -211,12 +228,21 @@ __device__ __forceinline__ void sl_loader(const SlPlanes &in, float4 (&ring)[SlC
 template <int NL, bool FULL, bool ACC, int LN = 32>
 __global__ void __launch_bounds__((SlCfg<NL, LN>::THREADS), (LN == 64 ? 2 : 1))
 k_hs_stream(SlPlanes in, float *__restrict__ Uo, float *__restrict__ Vo, int H, int W, int T, int tiles_x, int chunk_rows,
-            int zero_in) {
+            int zero_in, OfriPrio pr) {
     constexpr int SL_NS = SlCfg<NL, LN>::NS, SL_CR = SlCfg<NL, LN>::CR, SL_LAG = SlCfg<NL, LN>::LAG, SL_OX = SlCfg<NL, LN>::OX, SL_NL = NL;
     constexpr int SL_RX = SlCfg<NL, LN>::RX;
     __shared__ float4 ring[SL_NS][2][2][LN];      // ring[s]: input rows of stage s.  [row & 1][U|V][lane]
     __shared__ float4 coef[SL_CR][3][LN];         // [row slot][A|B|C][lane]
     const int tid = threadIdx.x;
+#ifdef OFRI_SL_TRACE
+    if (tid == 0 && blockIdx.x < SL_TRACE_MAX) {
+        g_sl_trace[3 * blockIdx.x] = wall_clock64();
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_sl_trace[3 * blockIdx.x + 2] = ((unsigned long long)xcc << 32) | hw;
+    }
+#endif
     // Workgroups go to the 8 XCDs round-robin by index, and each XCD has its own L2.  Renumber them so that an
     // XCD gets a run of neighbouring strips and chunks: the columns and fill rows that neighbours share are then
     // fetched from memory once per XCD instead of once per workgroup.
@@ -236,11 +262,11 @@ k_hs_stream(SlPlanes in, float *__restrict__ Uo, float *__restrict__ Vo, int H, 
     if (tid >= SL_NS * LN) {
         const bool edge = x0 < 0 || x0 + SL_RX > W;
         if (edge) {
-            if (zero_in) sl_loader<NL, LN, true, true>(in, ring, coef, tid - SL_NS * LN, x0, rho0, NS, H, W);
-            else sl_loader<NL, LN, true, false>(in, ring, coef, tid - SL_NS * LN, x0, rho0, NS, H, W);
+            if (zero_in) sl_loader<NL, LN, true, true>(in, ring, coef, tid - SL_NS * LN, x0, rho0, NS, H, W, pr);
+            else sl_loader<NL, LN, true, false>(in, ring, coef, tid - SL_NS * LN, x0, rho0, NS, H, W, pr);
         } else {
-            if (zero_in) sl_loader<NL, LN, false, true>(in, ring, coef, tid - SL_NS * LN, x0, rho0, NS, H, W);
-            else sl_loader<NL, LN, false, false>(in, ring, coef, tid - SL_NS * LN, x0, rho0, NS, H, W);
+            if (zero_in) sl_loader<NL, LN, false, true>(in, ring, coef, tid - SL_NS * LN, x0, rho0, NS, H, W, pr);
+            else sl_loader<NL, LN, false, false>(in, ring, coef, tid - SL_NS * LN, x0, rho0, NS, H, W, pr);
         }
     } else {
         // ---- stage half-wavefronts ---------------------------------------------------------------------
@@ -266,8 +292,12 @@ k_hs_stream(SlPlanes in, float *__restrict__ Uo, float *__restrict__ Vo, int H, 
                                      Vo + (long long)ro * W, ro >= ya && ro < yb, 2LL * W, ro + 2 >= ya && ro + 2 < yb); \
         __syncthreads();                                                                                              \
     }
-        for (int t = 0; t < NS; t += SL_PF) { SL_STEP(0) SL_STEP(1) SL_STEP(2) SL_STEP(3) SL_STEP(4) SL_STEP(5) }
+        OfriPrioState ps = ofri_prio_begin(pr, NS, blockIdx.x);
+        for (int t = 0; t < NS; t += SL_PF) { ofri_prio_turn(t, pr, ps); SL_STEP(0) SL_STEP(1) SL_STEP(2) SL_STEP(3) SL_STEP(4) SL_STEP(5) }
 #undef SL_STEP
+#ifdef OFRI_SL_TRACE
+        if (tid == 0 && blockIdx.x < SL_TRACE_MAX) g_sl_trace[3 * blockIdx.x + 1] = wall_clock64();
+#endif
     }
 }
 
@@ -334,12 +364,16 @@ static void sl_launch(ofri_ctx *ctx, const SlPlanes &in, float *uo, float *vo, i
     const int chunk_rows = ceil_div(H, nchunks);
     nchunks = ceil_div(H, chunk_rows);
     const int grid = tiles_x * nchunks, thr = Cfg::THREADS;
+    const int ncu = ofri_ctx_ncu(ctx), per_cu = ceil_div(grid, ncu);
+    // measured at 4096 x 4096 and 2048 x 2048: four priority levels, 8 turns per chunk for the 12-sweep launches (154 -> 140 us
+    // and 58 -> 52 us per launch), 6 for the deeper one (232 -> 232 and 76 -> 69 us)
+    const OfriPrio pr{ncu, per_cu > 1 ? 4 : 0, NL == SL_NL_MAIN ? 8 : 6};
     if (T == NL) {
-        if (acc) k_hs_stream<NL, true, true, LN><<<grid, thr, 0, ctx->stream>>>(in, uo, vo, H, W, T, tiles_x, chunk_rows, zero_in);
-        else k_hs_stream<NL, true, false, LN><<<grid, thr, 0, ctx->stream>>>(in, uo, vo, H, W, T, tiles_x, chunk_rows, zero_in);
+        if (acc) k_hs_stream<NL, true, true, LN><<<grid, thr, 0, ctx->stream>>>(in, uo, vo, H, W, T, tiles_x, chunk_rows, zero_in, pr);
+        else k_hs_stream<NL, true, false, LN><<<grid, thr, 0, ctx->stream>>>(in, uo, vo, H, W, T, tiles_x, chunk_rows, zero_in, pr);
     } else {
-        if (acc) k_hs_stream<NL, false, true, LN><<<grid, thr, 0, ctx->stream>>>(in, uo, vo, H, W, T, tiles_x, chunk_rows, zero_in);
-        else k_hs_stream<NL, false, false, LN><<<grid, thr, 0, ctx->stream>>>(in, uo, vo, H, W, T, tiles_x, chunk_rows, zero_in);
+        if (acc) k_hs_stream<NL, false, true, LN><<<grid, thr, 0, ctx->stream>>>(in, uo, vo, H, W, T, tiles_x, chunk_rows, zero_in, pr);
+        else k_hs_stream<NL, false, false, LN><<<grid, thr, 0, ctx->stream>>>(in, uo, vo, H, W, T, tiles_x, chunk_rows, zero_in, pr);
     }
 }
 // strips of 256 columns where two workgroups per CU still get long row chunks
