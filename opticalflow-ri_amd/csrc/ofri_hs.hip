@@ -227,15 +227,19 @@ static int hs_stream_path(ofri_ctx *ctx, const float *Uin, const float *Vin, flo
     const int per = ofri_hs_stream_sweeps(), odd = n_stream % per;
     const int tail = (ctx->hs_fuse == 0 && n_stream > per && odd >= 1 && odd <= ofri_hs_stream_deep_sweeps() - per) ? per + odd : 0;
     const int bulk = n_stream - tail;
-    ofri_ctx::ProfRec rec{};
-    OFRI_TRY(prof_begin(ctx, rec));
-    OFRI_TRY(ofri_sl_sweeps(ctx, set, bulk, rest == 0 && tail == 0, rest == 0 && tail == 0 && accumulate, Uout, Vout, rows, cols, &cur, &launches));
-    OFRI_TRY(prof_end(ctx, rec, rows, cols, launches, bulk));
+    // the deep launch goes first: it starts from the zero flow of a level without reading it, and the accumulating store is
+    // cheaper in a 12-sweep launch (two loader wavefronts per workgroup) than in the deep one
     if (tail > 0) {
         ofri_ctx::ProfRec rect{};
         OFRI_TRY(prof_begin(ctx, rect));
-        OFRI_TRY(ofri_sl_sweeps(ctx, set, tail, rest == 0, rest == 0 && accumulate, Uout, Vout, rows, cols, &cur, &launches, true));
+        OFRI_TRY(ofri_sl_sweeps(ctx, set, tail, rest == 0 && bulk == 0, rest == 0 && bulk == 0 && accumulate, Uout, Vout, rows, cols, &cur, &launches, true));
         OFRI_TRY(prof_end(ctx, rect, rows, cols, launches, tail));
+    }
+    if (bulk > 0) {
+        ofri_ctx::ProfRec rec{};
+        OFRI_TRY(prof_begin(ctx, rec));
+        OFRI_TRY(ofri_sl_sweeps(ctx, set, bulk, rest == 0, rest == 0 && accumulate, Uout, Vout, rows, cols, &cur, &launches));
+        OFRI_TRY(prof_end(ctx, rec, rows, cols, launches, bulk));
     }
     if (rest > 0) {
         const int Tmax = ofri_hs_fused_max_sweeps(), L = (rest + Tmax - 1) / Tmax;
