@@ -49,8 +49,10 @@ def parse():
                     "barriers) even with one rank: rehearsal of the N > 1 path on a one-GPU box")
     ap.add_argument("--with-transfer", action="store_true", help="also report the rate including H2D/D2H copies")
     ap.add_argument("--graph", action="store_true", help="replay the pair's launches from a captured HIP graph (piv_plan.FlowPlan)")
-    ap.add_argument("--in-flight", type=int, default=1, help="with --graph: pairs per step, each on its own context/stream "
+    ap.add_argument("--in-flight", type=int, default=0, help="with --graph: pairs per step, each on its own context/stream (default 1); "
+                    "with --batch: pairs in flight per GPU (default 3) "
                     "(small frames do not fill the GPU one pair at a time)")
+    ap.add_argument("--no-in-flight", action="store_true", help="skip the three-pairs-in-flight throughput figure")
     ap.add_argument("--batch", type=int, default=0, help="total number of pairs of the batch configuration (512 on 8 GPUs); 0 = headline")
     ap.add_argument("--chunk", type=int, default=8, help="with --batch: pairs per gather")
     ap.add_argument("--distinct", type=int, default=4, help="with --batch: distinct synthetic pairs generated per rank (cycled; "
@@ -203,14 +205,15 @@ def run_batch_config(args, rank, world, local, dist, torch):
     from piv_synth import synth_piv
     H = W = args.size
     dev = 0 if args.same_device else local
-    ctx, stream = piv_batch.torch_context(dev)
+    n_lanes = args.in_flight if args.in_flight > 0 else 3
+    lanes = piv_batch.flow_lanes(n_lanes, lambda c: piv_batch.hs_liushen_flow(c, (H, W), niter=args.niter, graph=True), dev)
+    (ctx, flow), more = lanes[0], lanes[1:]
     a, b = piv_batch.partition(args.batch, world)[rank]
     distinct = max(1, min(args.distinct, max(b - a, 1)))
     resident = []
     for k in range(distinct):
         f0, f1 = synth_piv(H, W, seed=a + k)
         resident.append((ctx.upload(f0, np.uint8), ctx.upload(f1, np.uint8)))
-    flow = piv_batch.hs_liushen_flow(ctx, (H, W), niter=args.niter, graph=True)
     pair_fn = lambda p: resident[(p - a) % distinct]
 
     def sync_all():
@@ -226,7 +229,7 @@ def run_batch_config(args, rank, world, local, dist, torch):
         sync_all()
         t0 = time.perf_counter()
         for _ in range(steps):
-            out = piv_batch.run_batch(args.batch, pair_fn, flow, ctx=ctx, chunk=args.chunk, gather=gather, shape=(H, W))
+            out = piv_batch.run_batch(args.batch, pair_fn, flow, ctx=ctx, chunk=args.chunk, gather=gather, shape=(H, W), lanes=more)
         sync_all()
         dt = time.perf_counter() - t0
         if dist is not None:
@@ -235,7 +238,7 @@ def run_batch_config(args, rank, world, local, dist, torch):
 
     for _ in range(args.warmup):
         piv_batch.run_batch(min(args.batch, world * args.chunk), lambda p: resident[0], flow, ctx=ctx, chunk=args.chunk,
-                            gather=dist is not None and not args.no_gather, shape=(H, W))
+                            gather=dist is not None and not args.no_gather, shape=(H, W), lanes=more)
     dt_g, out = timed(not args.no_gather, args.steps)
     ok = None
     if rank == 0 and out is not None:
@@ -256,7 +259,7 @@ def run_batch_config(args, rank, world, local, dist, torch):
                    "flow_gather": ("none" if (dist is None or args.no_gather) else
                                    "%s gather to rank 0 every %d pairs, overlapped with the next chunk" %
                                    ("rccl" if args.backend == "nccl" else args.backend, args.chunk)),
-                   "captured_graph": True, "gathered_shape_ok": ok},
+                   "captured_graph": True, "pairs_in_flight_per_gpu": n_lanes, "gathered_shape_ok": ok},
         "without_gather": {"value": px / dt_n / 1e6, "ms_per_step": dt_n / args.steps * 1e3},
         "ms_per_pair_per_gpu": dt_g / args.steps * 1e3 / max(1, -(-args.batch // world)),
     }
@@ -429,6 +432,34 @@ def main():
                        "hs_sweeps_per_launch": roof["sweeps_per_launch"] if roof else None},
             "roofline": roof,
         }
+    if rank == 0 and world == 1 and not args.graph and not args.no_in_flight:
+        # throughput figure beside the headline: three pairs in flight, each replayed from its own captured graph on its
+        # own stream (one pair's launches leave gaps and tails that another pair's fill); not `value`, which stays one
+        # pair per step with the roofline measured inside it
+        from piv_plan import FlowPlan
+        lanes = []
+        for k in range(3):
+            c = ctx if k == 0 else _ofri.Context(dev)
+            pk = FlowPlan((H, W), 3.4, lambda: HSOpticalFlowAlgoAdapter([21, 45], args.niter), pyramidalLevels=2, ctx=c, **opt_args)
+            pk.load(*((im0, im1) if k == 0 else synth_piv(H, W, seed=100 + k)))
+            c.sync()
+            lanes.append((c, pk))
+        def rounds(n):
+            for _ in range(n):
+                for _, pk in lanes:
+                    pk.run()
+            for c, _ in lanes:
+                c.sync()
+        rounds(2)
+        t = time.perf_counter()
+        rounds(args.steps)
+        dt3 = time.perf_counter() - t
+        result["three_pairs_in_flight"] = {"value": 3 * H * W * args.steps / dt3 / 1e6, "unit": "Mpix/s",
+                                           "ms_per_pair": dt3 / args.steps / 3 * 1e3, "captured_graphs": True}
+        for c, pk in lanes:
+            pk.close()
+            if c is not ctx:
+                c.close()
     if args.with_transfer and rank == 0 and world == 1:
         t = time.perf_counter()
         for i in range(3):

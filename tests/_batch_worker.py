@@ -34,6 +34,13 @@ def no_group():
         U, V = pyramidal_flow_device(ctx.upload(a), ctx.upload(b), 3.4, HSOpticalFlowAlgoAdapter([21, 45], 16), 2, 1, None)
         np.testing.assert_array_equal(got[p, 0], U.numpy())
         np.testing.assert_array_equal(got[p, 1], V.numpy())
+    # three pairs in flight: lane k takes the rank's pairs k, k + 3, ...; same fields in the same order
+    lanes = piv_batch.flow_lanes(2, lambda c: piv_batch.hs_liushen_flow(c, (H, W), niter=16, liushen=False, graph=True), 0)
+    torch.cuda.set_stream(stream)
+    out3 = piv_batch.run_batch(3, lambda p: resident[p], flow, ctx=ctx, chunk=2, lanes=lanes)
+    np.testing.assert_array_equal(out3.cpu().numpy(), got)
+    for _, f in lanes:
+        f.close()
     flow.close()
     print("BATCH-OK")
 
@@ -76,6 +83,13 @@ def main():
         # the same without the exchange: the rank's own block
         loc = piv_batch.run_batch(n_pairs, lambda p: frames[p], flow, ctx=ctx, chunk=chunk, gather=False)
         np.testing.assert_array_equal(loc.cpu().numpy(), got)
+        # several pairs in flight (each lane its own stream and graph), gathered chunk by chunk as before
+        lanes = piv_batch.flow_lanes(2, lambda c: piv_batch.hs_liushen_flow(c, (H, W), niter=niter, graph=graph), 0)
+        torch.cuda.set_stream(stream)
+        out3 = piv_batch.run_batch(n_pairs, lambda p: frames[p], flow, ctx=ctx, chunk=chunk, lanes=lanes)
+        np.testing.assert_array_equal(out3.cpu().numpy(), got, err_msg="lanes (graph=%s)" % graph)
+        for _, f in lanes:
+            f.close()
         flow.close()
     t = piv_batch.max_over_ranks(1.25, device="cuda" if backend == "nccl" else None)
     assert t == 1.25
