@@ -11,7 +11,7 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libofri_hip.so")
+LIB_PATH = os.environ.get("OFRI_LIB_PATH") or os.path.join(_HERE, "libofri_hip.so")     # OFRI_LIB_PATH: another build of the library
 
 
 class OfriError(RuntimeError):

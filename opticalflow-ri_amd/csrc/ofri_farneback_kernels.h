@@ -282,8 +282,11 @@ k_fb_window(const float *__restrict__ src, float *__restrict__ dst, float *__res
 // UM (with FLOW): the matrices of the next iteration are made from the new displacement on the spot (updateMatrices,
 // a per-pixel step) and stored to Mnext; the displacement itself is stored only where flowx is given.
 #define BW_TY 32
+#ifndef FB_W16_WAVES
+#define FB_W16_WAVES 3
+#endif
 template <int NP, int MODE, bool FLOW, bool UM = false>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, FB_W16_WAVES)
 k_fb_window16(const float *__restrict__ src, float *__restrict__ dst, float *__restrict__ flowx, float *__restrict__ flowy,
               int H, int W, FbTaps taps, int tiles_x, int ntiles, const float *__restrict__ R0 = nullptr,
               const float *__restrict__ R1 = nullptr, float *__restrict__ Mnext = nullptr) {
@@ -300,7 +303,7 @@ k_fb_window16(const float *__restrict__ src, float *__restrict__ dst, float *__r
     const int bx = (t % tiles_x) * BL_TX, by = (t / tiles_x) * BW_TY, tid = threadIdx.x;
     const size_t P = (size_t)H * W;
     const int ly = tid >> 4, xg = tid & 15;                                  // horizontal pass: row (and row + 16), group of 4 columns
-    float res[NP][NR][4];
+    float res[NP][NR][4] = {};
     // this thread's samples of a plane's 64 x 96 source tile: rows (tid>>5) + 8s, columns (tid&31) + 32q.
     // All loads of a plane are issued together, and the next plane's are issued before the current
     // plane is filtered, so their latency hides behind the arithmetic.
@@ -365,7 +368,9 @@ k_fb_window16(const float *__restrict__ src, float *__restrict__ dst, float *__r
                     float sm = c[KSH + k - i] + c[KSH + k + i];
                     acc += MODE == 0 ? sm * taps.k[i] : sm;
                 }
-                res[p][h][k] = acc;
+                // res indexed by h would live in scratch memory (h is a loop variable): select into registers instead
+#pragma unroll
+                for (int hh = 0; hh < NR; ++hh) res[p][hh][k] = h == hh ? acc : res[p][hh][k];
             }
         }
         // next plane: tin is rewritten before, tv after the barrier that follows the tin load
