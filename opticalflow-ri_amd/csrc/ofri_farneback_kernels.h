@@ -83,19 +83,30 @@ __global__ void __launch_bounds__(256)
 k_fb_blur3_polyexp(const float *__restrict__ src, float *__restrict__ dst, int H, int W, float k0, float k1, FbPoly c) {
     constexpr int SW = BP_TX + 2 * N + 2, SH = BP_TY + 2 * N + 2;     // source tile
     constexpr int BW = BP_TX + 2 * N, BH = BP_TY + 2 * N;             // blurred tile: image rows by-N .., columns bx-N ..
-    __shared__ float pool[SH * SW + BH * SW];                         // source tile + vertical pass; later r0, r1, r2
+    constexpr int NQ = (4 + 2 * N + 3) / 4, BWP = (BP_TX + 4 * NQ - 4 + 3) & ~3;   // 16-byte groups of a window; row pitch of r0, r1, r2
+    __shared__ __attribute__((aligned(16))) float pool[SH * SW + BH * SW];   // source tile + vertical pass; later r0, r1, r2
     __shared__ float B[BH][BW];
-    static_assert(3 * BP_TY * BW <= SH * SW + BH * SW, "the three partial-sum planes fit where the blur's tiles were");
+    static_assert(3 * BP_TY * BWP <= SH * SW + BH * SW && BWP >= BW, "the three partial-sum planes fit where the blur's tiles were");
     float (*S)[SW] = reinterpret_cast<float (*)[SW]>(pool);
     float (*V)[SW] = reinterpret_cast<float (*)[SW]>(pool + SH * SW);
-    float (*r0)[BW] = reinterpret_cast<float (*)[BW]>(pool);
-    float (*r1)[BW] = reinterpret_cast<float (*)[BW]>(pool + BP_TY * BW);
-    float (*r2)[BW] = reinterpret_cast<float (*)[BW]>(pool + 2 * BP_TY * BW);
+    float (*r0)[BWP] = reinterpret_cast<float (*)[BWP]>(pool);
+    float (*r1)[BWP] = reinterpret_cast<float (*)[BWP]>(pool + BP_TY * BWP);
+    float (*r2)[BWP] = reinterpret_cast<float (*)[BWP]>(pool + 2 * BP_TY * BWP);
     const int bx = blockIdx.x * BP_TX, by = blockIdx.y * BP_TY, tid = threadIdx.x;
-    for (int i = tid; i < SH * SW; i += 256) {
-        const int ly = i / SW, lx = i - ly * SW;
-        const int y = fb_idx(by - N - 1 + ly, H - 1), x = fb_idx(bx - N - 1 + lx, W - 1);
-        S[ly][lx] = src[(size_t)y * W + x];
+    {   // all of a thread's loads are issued before the first one is used (one at a time they cost a memory latency each)
+        constexpr int NLD = (SH * SW + 255) / 256;
+        float pre[NLD];
+#pragma unroll
+        for (int e = 0; e < NLD; ++e) {
+            const int i = min(tid + 256 * e, SH * SW - 1), ly = i / SW, lx = i - ly * SW;
+            const int y = fb_idx(by - N - 1 + ly, H - 1), x = fb_idx(bx - N - 1 + lx, W - 1);
+            pre[e] = src[(size_t)y * W + x];
+        }
+#pragma unroll
+        for (int e = 0; e < NLD; ++e) {
+            const int i = tid + 256 * e;
+            if (i < SH * SW) pool[i] = pre[e];
+        }
     }
     __syncthreads();
     for (int i = tid; i < BH * SW; i += 256) {
@@ -113,45 +124,84 @@ k_fb_blur3_polyexp(const float *__restrict__ src, float *__restrict__ dst, int H
     }
     __syncthreads();
     // expansion, vertical pass; rows clamped (:98-99), columns clamped (:89).  Entries of B outside the image are never read.
-    for (int i = tid; i < BP_TY * BW; i += 256) {
-        const int ly = i / BW, lx = i - ly * BW;
-        const int y = by + ly, col = clampi(bx + lx - N, 0, W - 1) - (bx - N);
-        float a = 0.f, b = 0.f, d = 0.f;
-        if (y < H) {
-            a = B[ly + N][col] * c.g[0];
+    // A thread takes four stacked outputs of a column from a window of 4 + 2N blurred values in registers (a value of
+    // the window serves every output that reaches it: the clamp belongs to the image row, not to the tap).
+    static_assert(BP_TY % 4 == 0, "row groups of four");
+    for (int i = tid; i < (BP_TY / 4) * BW; i += 256) {
+        const int rg = i / BW, lx = i - rg * BW;
+        const int col = clampi(bx + lx - N, 0, W - 1) - (bx - N);
+        float w[4 + 2 * N];
 #pragma unroll
-            for (int k = 1; k <= N; ++k) {
-                float t0 = B[max(y - k, 0) - (by - N)][col];
-                float t1 = B[min(y + k, H - 1) - (by - N)][col];
-                a += c.g[k] * (t0 + t1);
-                b += c.xg[k] * (t1 - t0);
-                d += c.xxg[k] * (t0 + t1);
+        for (int j = 0; j < 4 + 2 * N; ++j) w[j] = B[clampi(by + 4 * rg + j - N, 0, H - 1) - (by - N)][col];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float a = 0.f, b = 0.f, d = 0.f;
+            if (by + 4 * rg + r < H) {
+                a = w[r + N] * c.g[0];
+#pragma unroll
+                for (int k = 1; k <= N; ++k) {
+                    const float t0 = w[r + N - k], t1 = w[r + N + k];
+                    a += c.g[k] * (t0 + t1);
+                    b += c.xg[k] * (t1 - t0);
+                    d += c.xxg[k] * (t0 + t1);
+                }
             }
+            r0[4 * rg + r][lx] = a; r1[4 * rg + r][lx] = b; r2[4 * rg + r][lx] = d;
         }
-        r0[ly][lx] = a; r1[ly][lx] = b; r2[ly][lx] = d;
     }
     __syncthreads();
-    for (int i = tid; i < BP_TY * BP_TX; i += 256) {
-        const int ly = i / BP_TX, lx = i - ly * BP_TX;
-        const int y = by + ly, x = bx + lx;
-        if (y >= H || x >= W) continue;
-        const float *p0 = &r0[ly][lx + N], *p1 = &r1[ly][lx + N], *p2 = &r2[ly][lx + N];
-        float b1 = c.g[0] * p0[0], b3 = c.g[0] * p1[0], b5 = c.g[0] * p2[0], b2 = 0.f, b4 = 0.f, b6 = 0.f;
+    // horizontal pass: four adjacent outputs per thread from windows of 4 + 2N partial sums (16-byte LDS reads)
+    static_assert(BP_TY * BP_TX == 4 * 256 && BWP % 4 == 0 && 4 + 2 * N <= 4 * NQ, "four outputs per thread");
+    {
+        const int ly = tid >> 4, xg = tid & 15, y = by + ly;
+        float c0[4 * NQ], c1[4 * NQ], c2[4 * NQ];
+        const float4 *q0 = reinterpret_cast<const float4 *>(&r0[ly][4 * xg]), *q1 = reinterpret_cast<const float4 *>(&r1[ly][4 * xg]);
+        const float4 *q2 = reinterpret_cast<const float4 *>(&r2[ly][4 * xg]);
 #pragma unroll
-        for (int k = 1; k <= N; ++k) {
-            b1 += (p0[k] + p0[-k]) * c.g[k];
-            b4 += (p0[k] + p0[-k]) * c.xxg[k];
-            b2 += (p0[k] - p0[-k]) * c.xg[k];
-            b3 += (p1[k] + p1[-k]) * c.g[k];
-            b6 += (p1[k] - p1[-k]) * c.xg[k];
-            b5 += (p2[k] + p2[-k]) * c.g[k];
+        for (int q = 0; q < NQ; ++q) {
+            const float4 v0 = q0[q], v1 = q1[q], v2 = q2[q];
+            c0[4 * q] = v0.x; c0[4 * q + 1] = v0.y; c0[4 * q + 2] = v0.z; c0[4 * q + 3] = v0.w;
+            c1[4 * q] = v1.x; c1[4 * q + 1] = v1.y; c1[4 * q + 2] = v1.z; c1[4 * q + 3] = v1.w;
+            c2[4 * q] = v2.x; c2[4 * q + 1] = v2.y; c2[4 * q + 2] = v2.z; c2[4 * q + 3] = v2.w;
         }
-        size_t o = (size_t)y * W + x, P = (size_t)H * W;
-        dst[o] = b3 * c.ig[0];
-        dst[P + o] = b2 * c.ig[0];
-        dst[2 * P + o] = b1 * c.ig[1] + b5 * c.ig[2];
-        dst[3 * P + o] = b1 * c.ig[1] + b4 * c.ig[2];
-        dst[4 * P + o] = b6 * c.ig[3];
+        float o0[4], o1[4], o2[4], o3[4], o4[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float *p0 = &c0[r + N], *p1 = &c1[r + N], *p2 = &c2[r + N];
+            float b1 = c.g[0] * p0[0], b3 = c.g[0] * p1[0], b5 = c.g[0] * p2[0], b2 = 0.f, b4 = 0.f, b6 = 0.f;
+#pragma unroll
+            for (int k = 1; k <= N; ++k) {
+                b1 += (p0[k] + p0[-k]) * c.g[k];
+                b4 += (p0[k] + p0[-k]) * c.xxg[k];
+                b2 += (p0[k] - p0[-k]) * c.xg[k];
+                b3 += (p1[k] + p1[-k]) * c.g[k];
+                b6 += (p1[k] - p1[-k]) * c.xg[k];
+                b5 += (p2[k] + p2[-k]) * c.g[k];
+            }
+            o0[r] = b3 * c.ig[0];
+            o1[r] = b2 * c.ig[0];
+            o2[r] = b1 * c.ig[1] + b5 * c.ig[2];
+            o3[r] = b1 * c.ig[1] + b4 * c.ig[2];
+            o4[r] = b6 * c.ig[3];
+        }
+        const int x = bx + 4 * xg;
+        const size_t P = (size_t)H * W;
+        if (y < H) {
+            const size_t o = (size_t)y * W + x;
+            if ((W & 3) == 0 && x + 3 < W && (((size_t)dst) & 15) == 0) {
+                *reinterpret_cast<float4 *>(dst + o) = make_float4(o0[0], o0[1], o0[2], o0[3]);
+                *reinterpret_cast<float4 *>(dst + P + o) = make_float4(o1[0], o1[1], o1[2], o1[3]);
+                *reinterpret_cast<float4 *>(dst + 2 * P + o) = make_float4(o2[0], o2[1], o2[2], o2[3]);
+                *reinterpret_cast<float4 *>(dst + 3 * P + o) = make_float4(o3[0], o3[1], o3[2], o3[3]);
+                *reinterpret_cast<float4 *>(dst + 4 * P + o) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (x + r >= W) continue;
+                    dst[o + r] = o0[r]; dst[P + o + r] = o1[r]; dst[2 * P + o + r] = o2[r]; dst[3 * P + o + r] = o3[r]; dst[4 * P + o + r] = o4[r];
+                }
+            }
+        }
     }
 }
 
