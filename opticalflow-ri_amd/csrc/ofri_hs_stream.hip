@@ -105,18 +105,21 @@ struct SlStage {                 // registers of one pipeline stage (one lane)
     SlRow in0, in1;              // input rows rA-1, rA
     SlRow mid0, mid1;            // rows rA-2, rA-1 of the stage's first sweep
     SlCoef gprev;                // coefficients of row rA-1
-    float4 au0, av0, au1, av1;   // (accumulating store) what the destination holds in the next two rows to store
+    float4 au0, av0, au1, av1, au2, av2;   // (accumulating store) what the destination holds in the next three rows to store
     int rA;                      // row the first sweep produces at this step
     int cslot;                   // coefficient ring slot of row rA
 };
 
 // one step of a stage: first sweep at row rA, second sweep at row rA-1.  ACC: the last stage adds its row to what the
-// destination holds; those values are fetched two steps (rows) ahead (row2: the row two below rowU, rowV is stored later).
-template <int NL, int LN, bool FULL, bool ACC>
+// destination holds; those values are fetched three steps (rows) ahead by every lane of the wavefront that holds the last
+// stage (LASTW), from addresses clamped into the chunk (accU, accV: the row three below rowU, rowV; lane_safe: the lane's
+// columns clamped into the image), so that the loads are unconditional: a conditional load makes the rotation of the
+// three registers a real move, which waits for the load just issued, and the compiler then waits for every store as well.
+template <int NL, int LN, bool FULL, bool ACC, bool LASTW>
 __device__ __forceinline__ void sl_stage_step(SlStage &st, float4 (&ring)[SlCfg<NL, LN>::NS][2][2][LN],
                                               float4 (&coef)[SlCfg<NL, LN>::CR][3][LN], int stage, int l, bool passA, bool passB,
                                               bool store_lane, int lane_off, float *__restrict__ rowU, float *__restrict__ rowV,
-                                              bool row_ok, long long row2, bool row2_ok) {
+                                              bool row_ok, const float *__restrict__ accU, const float *__restrict__ accV, int lane_safe) {
     constexpr int SL_NS = SlCfg<NL, LN>::NS, SL_CR = SlCfg<NL, LN>::CR;
     // newest input row rA+1, written one step ago
     const float4 nu4 = ring[stage][(st.rA + 1) & 1][0][l], nv4 = ring[stage][(st.rA + 1) & 1][1][l];
@@ -137,19 +140,21 @@ __device__ __forceinline__ void sl_stage_step(SlStage &st, float4 (&ring)[SlCfg<
         out = sl_sweep<FULL>(st.mid0, st.mid1, mid2, st.gprev, passB);         // row rA-1 of the second sweep
     }
     const int rB = st.rA - 1;
+    float4 a0u, a0v;
+    if (ACC && LASTW) {
+        a0u = st.au0; a0v = st.av0;
+        st.au0 = st.au1; st.av0 = st.av1; st.au1 = st.au2; st.av1 = st.av2;
+        st.au2 = *reinterpret_cast<const float4 *>(accU + lane_safe);
+        st.av2 = *reinterpret_cast<const float4 *>(accV + lane_safe);
+    }
     if (stage < SL_NS - 1) {
         ring[stage + 1][rB & 1][0][l] = make_float4(out.u[0], out.u[1], out.u[2], out.u[3]);
         ring[stage + 1][rB & 1][1][l] = make_float4(out.v[0], out.v[1], out.v[2], out.v[3]);
     } else {
         float4 ou = make_float4(out.u[0], out.u[1], out.u[2], out.u[3]), ov = make_float4(out.v[0], out.v[1], out.v[2], out.v[3]);
-        if (ACC) {
-            ou = make_float4(__fadd_rn(st.au0.x, ou.x), __fadd_rn(st.au0.y, ou.y), __fadd_rn(st.au0.z, ou.z), __fadd_rn(st.au0.w, ou.w));
-            ov = make_float4(__fadd_rn(st.av0.x, ov.x), __fadd_rn(st.av0.y, ov.y), __fadd_rn(st.av0.z, ov.z), __fadd_rn(st.av0.w, ov.w));
-            st.au0 = st.au1; st.av0 = st.av1;
-            if (store_lane && row2_ok) {
-                st.au1 = *reinterpret_cast<const float4 *>(rowU + row2 + lane_off);
-                st.av1 = *reinterpret_cast<const float4 *>(rowV + row2 + lane_off);
-            }
+        if (ACC && LASTW) {
+            ou = make_float4(__fadd_rn(a0u.x, ou.x), __fadd_rn(a0u.y, ou.y), __fadd_rn(a0u.z, ou.z), __fadd_rn(a0u.w, ou.w));
+            ov = make_float4(__fadd_rn(a0v.x, ov.x), __fadd_rn(a0v.y, ov.y), __fadd_rn(a0v.z, ov.z), __fadd_rn(a0v.w, ov.w));
         }
         if (store_lane && row_ok) {
             // rowU, rowV: the output row of this step (the same for the whole workgroup, so its address is scalar work)
@@ -278,22 +283,43 @@ k_hs_stream(SlPlanes in, float *__restrict__ Uo, float *__restrict__ Vo, int H, 
             st.mid0.u[k] = st.mid0.v[k] = st.mid1.u[k] = st.mid1.v[k] = 0.f;
         }
         st.gprev.fx = st.gprev.fy = st.gprev.ft = make_float4(0.f, 0.f, 0.f, 0.f);
-        st.au0 = st.av0 = st.au1 = st.av1 = make_float4(0.f, 0.f, 0.f, 0.f);
+        st.au0 = st.av0 = st.au1 = st.av1 = st.au2 = st.av2 = make_float4(0.f, 0.f, 0.f, 0.f);
         st.rA = rho0 - 2 - 3 * stage;
         st.cslot = (st.rA + 64 * SL_CR) % SL_CR;
         const bool passA = 2 * stage >= T, passB = 2 * stage + 1 >= T;    // fewer than NL sweeps asked: copy rows through
         const bool store_lane = l >= SL_NL / 4 && l < LN - SL_NL / 4 && (x0 + 4 * l) < W;
         const int lane_off = x0 + 4 * l;
+        const int lane_safe = min(max(lane_off, 0), W - 4);
+        // the wavefront that holds the last stage (it alone touches the destination)
+        const bool lastw = __builtin_amdgcn_readfirstlane(tid / 64) == (SL_NS * LN - 1) / 64;
         // six steps per round (NS is a multiple): the row registers rotate by renaming instead of moves
-#define SL_STEP(U_)                                                                                                   \
+#define SL_STEP(U_, LASTW_)                                                                                           \
     {                                                                                                                 \
         const int ro = rho0 - SL_LAG + t + (U_);          /* row the last stage finishes at this step */              \
-        sl_stage_step<NL, LN, FULL, ACC>(st, ring, coef, stage, l, passA, passB, store_lane, lane_off, Uo + (long long)ro * W, \
-                                     Vo + (long long)ro * W, ro >= ya && ro < yb, 2LL * W, ro + 2 >= ya && ro + 2 < yb); \
+        const long long ra = (long long)min(max(ro + 3, ya), yb - 1) * W;      /* row whose old values are fetched */  \
+        sl_stage_step<NL, LN, FULL, ACC, LASTW_>(st, ring, coef, stage, l, passA, passB, store_lane, lane_off, Uo + (long long)ro * W, \
+                                     Vo + (long long)ro * W, ro >= ya && ro < yb, Uo + ra, Vo + ra, lane_safe);        \
         __syncthreads();                                                                                              \
     }
         OfriPrioState ps = ofri_prio_begin(pr, NS, blockIdx.x);
-        for (int t = 0; t < NS; t += SL_PF) { ofri_prio_turn(t, pr, ps); SL_STEP(0) SL_STEP(1) SL_STEP(2) SL_STEP(3) SL_STEP(4) SL_STEP(5) }
+        if (ACC && lastw) {
+            // rows ro, ro + 1, ro + 2 of the first step (clamped into the chunk: what is fetched for rows outside is not used)
+            const int r0c = rho0 - SL_LAG;
+            const long long q0 = (long long)min(max(r0c, ya), yb - 1) * W, q1 = (long long)min(max(r0c + 1, ya), yb - 1) * W,
+                            q2 = (long long)min(max(r0c + 2, ya), yb - 1) * W;
+            st.au0 = *reinterpret_cast<const float4 *>(Uo + q0 + lane_safe); st.av0 = *reinterpret_cast<const float4 *>(Vo + q0 + lane_safe);
+            st.au1 = *reinterpret_cast<const float4 *>(Uo + q1 + lane_safe); st.av1 = *reinterpret_cast<const float4 *>(Vo + q1 + lane_safe);
+            st.au2 = *reinterpret_cast<const float4 *>(Uo + q2 + lane_safe); st.av2 = *reinterpret_cast<const float4 *>(Vo + q2 + lane_safe);
+            for (int t = 0; t < NS; t += SL_PF) {
+                ofri_prio_turn(t, pr, ps);
+                SL_STEP(0, true) SL_STEP(1, true) SL_STEP(2, true) SL_STEP(3, true) SL_STEP(4, true) SL_STEP(5, true)
+            }
+        } else {
+            for (int t = 0; t < NS; t += SL_PF) {
+                ofri_prio_turn(t, pr, ps);
+                SL_STEP(0, false) SL_STEP(1, false) SL_STEP(2, false) SL_STEP(3, false) SL_STEP(4, false) SL_STEP(5, false)
+            }
+        }
 #undef SL_STEP
 #ifdef OFRI_SL_TRACE
         if (tid == 0 && blockIdx.x < SL_TRACE_MAX) g_sl_trace[3 * blockIdx.x + 1] = wall_clock64();

@@ -11,10 +11,12 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "opticalflow-ri_amd", "csrc")
 FLAGS = "-O3 -std=c++17 --offload-arch=gfx950 -Wno-unused-function -ffp-contract=on -fno-slp-vectorize --cuda-device-only -S".split()
-files = sys.argv[1:] or sorted(glob.glob(os.path.join(SRC, "*.hip")))
+files = [os.path.abspath(a) for a in sys.argv[1:]] or sorted(glob.glob(os.path.join(SRC, "*.hip")))
 for f in files:
     out = "/tmp/_isa_%s.s" % os.path.basename(f)
-    subprocess.run(["/opt/rocm/bin/hipcc"] + FLAGS + [f, "-o", out], cwd=SRC, stderr=subprocess.DEVNULL)
+    if os.path.exists(out):
+        os.remove(out)
+    subprocess.run(["/opt/rocm/bin/hipcc"] + FLAGS + [f, "-o", out], cwd=SRC, stderr=subprocess.DEVNULL, check=True)
     txt = open(out).read()
     for m in re.finditer(r"^(_Z\w+):[^\n]*\n(.*?)s_endpgm", txt, re.S | re.M):
         name = subprocess.run(["c++filt", m.group(1)], stdout=subprocess.PIPE, universal_newlines=True).stdout.strip().split("(")[0][:90]
