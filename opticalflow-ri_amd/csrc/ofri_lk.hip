@@ -238,10 +238,19 @@ k_lk_tile(const float *__restrict__ I, const float *__restrict__ J, const float 
     // ---- first image with a one-pixel apron (in sJ's space), then gradients
     {
         float (*tI)[LKT_SW + 2] = reinterpret_cast<float (*)[LKT_SW + 2]>(sJ);
-        for (int t = tid; t < (LKT_SH + 2) * (LKT_SW + 2); t += 256) {
-            const int ly = t / (LKT_SW + 2), lx = t - ly * (LKT_SW + 2);
+        // a thread's loads are issued together (one per loop round would cost a memory latency each)
+        constexpr int NI = ((LKT_SH + 2) * (LKT_SW + 2) + 255) / 256;
+        float pre[NI];
+#pragma unroll
+        for (int e = 0; e < NI; ++e) {
+            const int t = min(tid + 256 * e, (LKT_SH + 2) * (LKT_SW + 2) - 1), ly = t / (LKT_SW + 2), lx = t - ly * (LKT_SW + 2);
             const int yy = clampi(ty0 - LKT_HW - 1 + ly, 0, H - 1), xx = clampi(tx0 - LKT_HW - 1 + lx, 0, W - 1);
-            tI[ly][lx] = I[(size_t)yy * W + xx];
+            pre[e] = I[(size_t)yy * W + xx];
+        }
+#pragma unroll
+        for (int e = 0; e < NI; ++e) {
+            const int t = tid + 256 * e;
+            if (t < (LKT_SH + 2) * (LKT_SW + 2)) sJ[t] = pre[e];           // tI[ly][lx] is sJ[t]
         }
         if (tid == 0) {         // the tile's central pixel (clamped into the image) gives the neighbourhood's displacement
             const size_t c = (size_t)min(ty0 + LKT_PY / 2, H - 1) * W + min(tx0 + LKT_PX / 2, W - 1);
@@ -263,10 +272,23 @@ k_lk_tile(const float *__restrict__ I, const float *__restrict__ J, const float 
     }
     // ---- second image around the displaced tile
     const int jx0 = tx0 - LKT_HW - LKT_R + centre[0], jy0 = ty0 - LKT_HW - LKT_R + centre[1];
-    for (int t = tid; t < LKT_JH * LKT_JW; t += 256) {
-        const int ly = t / LKT_JW, lx = t - ly * LKT_JW;
-        const int yy = clampi(jy0 + ly, 0, H - 1), xx = clampi(jx0 + lx, 0, W - 1);
-        sJ[ly * LKT_JP + lx] = J[(size_t)yy * W + xx];
+    {
+        constexpr int NJ = (LKT_JH * LKT_JW + 255) / 256, NB = 8;          // in batches of eight loads
+#pragma unroll
+        for (int b0 = 0; b0 < NJ; b0 += NB) {
+            float pre[NB];
+#pragma unroll
+            for (int e = 0; e < NB; ++e) {
+                const int t = min(tid + 256 * (b0 + e), LKT_JH * LKT_JW - 1), ly = t / LKT_JW, lx = t - ly * LKT_JW;
+                const int yy = clampi(jy0 + ly, 0, H - 1), xx = clampi(jx0 + lx, 0, W - 1);
+                pre[e] = J[(size_t)yy * W + xx];
+            }
+#pragma unroll
+            for (int e = 0; e < NB; ++e) {
+                const int t = tid + 256 * (b0 + e), ly = t / LKT_JW, lx = t - ly * LKT_JW;
+                if (t < LKT_JH * LKT_JW) sJ[ly * LKT_JP + lx] = pre[e];
+            }
+        }
     }
     __syncthreads();
 
