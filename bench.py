@@ -265,8 +265,19 @@ def run_batch_config(args, rank, world, local, dist, torch):
     }
 
 
+def emit(result, real_stdout):
+    """The one JSON line, on the process's original standard output."""
+    sys.stdout.flush()
+    os.write(real_stdout, (json.dumps(result) + "\n").encode())
+
+
 def main():
     args = parse()
+    # Everything but the result line goes to standard error: libraries print banners to file descriptor 1 (RCCL its
+    # version block when the first communicator is made), and the contract is one JSON line on standard output.
+    real_stdout = os.dup(1)
+    sys.stdout.flush()
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -294,7 +305,7 @@ def main():
         result = run_batch_config(args, rank, world, local, dist, torch)
         if rank == 0:
             result["cpu_baseline"] = None
-            print(json.dumps(result))
+            emit(result, real_stdout)
         if multi:
             dist.barrier()
             dist.destroy_process_group()
@@ -493,7 +504,7 @@ def main():
         sp.close()
     if rank == 0:
         result["cpu_baseline"] = cpu
-        print(json.dumps(result))
+        emit(result, real_stdout)
     if multi:
         dist.barrier()
         dist.destroy_process_group()

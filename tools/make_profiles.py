@@ -132,7 +132,7 @@ shutil.copy(os.path.join(src, "stats", "bench_kernel_stats.csv"), os.path.join(d
 paths_rows = trace(os.path.join(src, "paths_stats", "paths_kernel_trace.csv"))
 write_stats(paths_rows, tag + "_paths_kernel_stats.csv", False)
 for f in ("bench_under_rocprof.json", "bench_default.json", "bench_paths.txt", "bench_with_transfer.json", "bench_batch64.json",
-          "bench_batch64_rccl_world1.json", "ls_modes.txt"):
+          "bench_batch64_rccl_world1.json", "bench_batch64_one_in_flight.json", "ls_modes.txt"):
     if os.path.exists(os.path.join(src, f)):
         shutil.copy(os.path.join(src, f), os.path.join(dst, tag + "_" + f))
 
@@ -146,7 +146,7 @@ traffic = {}
 for r in t1 + t2:
     name = r[0]
     key = None
-    if name.startswith("k_hs_stream<12, true, false>"):
+    if name.startswith("k_hs_stream<12, true, false"):
         key = "k_hs_stream@" + r[2]
     elif name.startswith("k_hs_stream<16"):
         key = "k_hs_stream_deep@" + r[2]
@@ -167,7 +167,7 @@ s2, m2 = sq_table("paths_sq", paths_rows, "bench_paths.py", "python3 bench_paths
 open(os.path.join(dst, tag + "_pmc_sq.md"), "w").write("\n".join(["# Instruction issue per kernel from a rocprofv3 SQ counter pass (%s)" % tag, ""] + m1 + [""] + m2) + "\n")
 sq = {}
 for r in s1:
-    if r["kernel"].startswith("k_hs_stream<12, true, false>"):
+    if r["kernel"].startswith("k_hs_stream<12, true, false"):
         sq["k_hs_stream@" + r["level"]] = {k: round(r[k], 4) for k in ("valu_of_wave_cycles", "any_of_wave_cycles", "waves_per_simd", "simd_valu_issue", "simd_any_issue")}
 json.dump(sq, open(os.path.join(dst, "pmc_sq.json"), "w"), indent=1)
 print(json.dumps(traffic))
