@@ -3,8 +3,9 @@
 
 One step = one frame pair through the whole hot path with the reference's example parameters
 (Gaussian pre-filter Fs 3.4, 2 pyramid levels, alphas [21, 45], 100 Jacobi sweeps per level), inputs
-already resident in HBM as float32.  N GPUs = N ranks, each with its own pairs (weak scaling); with
-N > 1 every pair's flow field is gathered to rank 0 over RCCL, overlapped with the next pair.
+already resident in HBM as float32.  N GPUs = N ranks, each with its own pairs (weak scaling): the pairs are
+independent, so the timed path has no exchange between ranks (barrier before and after, time = the slowest rank's);
+``--gather`` adds the asynchronous gather of every pair's flow field to rank 0 over RCCL, overlapped with the next pair.
 
     python bench.py --gpus 1 --steps 10 --warmup 2
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
@@ -40,7 +41,10 @@ def parse():
     ap.add_argument("--fuse", type=int, default=0, help="Jacobi sweeps per launch (0 = automatic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-one-core-only", action="store_true", help="skip the all-cores leg of the CPU baseline")
-    ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--no-gather", action="store_true", help="with --batch: leave out the gather of the flow fields to rank 0")
+    ap.add_argument("--gather", action="store_true", help="headline mode with N > 1: also send every pair's flow field to rank 0 "
+                    "(asynchronous RCCL gather overlapped with the next pair); off by default: the pairs are independent and "
+                    "the timed path has no exchange step")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--same-device", action="store_true", help="all ranks compute on GPU 0 (rehearsal on a one-GPU box)")
     ap.add_argument("--liushen", action="store_true", help="add the Liu-Shen refinement (h = 5, Fs_opt 0.48) after Horn-Schunck on "
@@ -338,7 +342,7 @@ def main():
 
     # Every pair's flow field goes to rank 0 (the only exchange of the job).  The gather of pair i runs
     # on a side stream while pair i+1 is computed; two send buffers alternate.
-    gather = multi and not args.no_gather
+    gather = multi and args.gather
     gather_note = "none"
     pending = []
     if gather:
