@@ -32,6 +32,8 @@ struct LsBufs { float *u[5], *v[5]; };
 
 // ---- set-up ------------------------------------------------------------------------------------
 #define LS_MAX_PARTS 512
+#define LSS_TX 64                        // tile of k_ls_setup (its block shape)
+#define LSS_TY 4
 __device__ inline float ls_wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_down(v, o, 64));
     return v;
@@ -41,6 +43,21 @@ __global__ void __launch_bounds__(256) k_ls_max2(const float *__restrict__ a, co
     __shared__ float sm[2][4];
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, st = (size_t)gridDim.x * blockDim.x;
     float ma = -INFINITY, mb = -INFINITY;
+    if (((((size_t)a) | ((size_t)b)) & 15) == 0) {          // 16-byte loads, four of each image in flight per thread
+        const float4 *a4 = reinterpret_cast<const float4 *>(a), *b4 = reinterpret_cast<const float4 *>(b);
+        const size_t n4 = n / 4;
+        for (; i + st < n4; i += 2 * st) {
+            const float4 p = a4[i], q = a4[i + st], r = b4[i], t = b4[i + st];
+            ma = fmaxf(fmaxf(fmaxf(ma, p.x), fmaxf(p.y, p.z)), fmaxf(fmaxf(p.w, q.x), fmaxf(fmaxf(q.y, q.z), q.w)));
+            mb = fmaxf(fmaxf(fmaxf(mb, r.x), fmaxf(r.y, r.z)), fmaxf(fmaxf(r.w, t.x), fmaxf(fmaxf(t.y, t.z), t.w)));
+        }
+        for (; i < n4; i += st) {
+            const float4 p = a4[i], r = b4[i];
+            ma = fmaxf(fmaxf(fmaxf(ma, p.x), fmaxf(p.y, p.z)), p.w);
+            mb = fmaxf(fmaxf(fmaxf(mb, r.x), fmaxf(r.y, r.z)), r.w);
+        }
+        i = 4 * n4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x;      // the last n % 4 values
+    }
     for (; i < n; i += st) { ma = fmaxf(ma, a[i]); mb = fmaxf(mb, b[i]); }
     ma = ls_wave_max(ma); mb = ls_wave_max(mb);
     if ((threadIdx.x & 63) == 0) { sm[0][threadIdx.x >> 6] = ma; sm[1][threadIdx.x >> 6] = mb; }
@@ -71,14 +88,34 @@ k_ls_setup(const float *__restrict__ im1, const float *__restrict__ im2, const f
     if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
         state->err = 1e8; state->iters = 0; state->done[0] = state->done[1] = 0; state->result = first_src; state->redo = 0; state->redo_src = 0;
     }
-    int x = blockIdx.x * blockDim.x + threadIdx.x;
-    int y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= W || y >= H) return;
     const float m1 = fmaxf(fmaxf(sm[0][0], sm[0][1]), fmaxf(sm[0][2], sm[0][3])), m2 = fmaxf(fmaxf(sm[1][0], sm[1][1]), fmaxf(sm[1][2], sm[1][3]));
+    // normalised tile with a one-pixel apron ('nearest' border): every pixel is divided once, not once per neighbour that
+    // reads it (the set-up was bound by these divisions)
+    __shared__ float t1[LSS_TY + 2][LSS_TX + 2], t2[LSS_TY + 2][LSS_TX + 2];
+    const int bx = blockIdx.x * LSS_TX, by = blockIdx.y * LSS_TY;
+    {
+        constexpr int NT = (LSS_TY + 2) * (LSS_TX + 2), NLD = (NT + 255) / 256;
+        float p1[NLD], p2[NLD];
+#pragma unroll
+        for (int e = 0; e < NLD; ++e) {
+            const int i = min(tid + 256 * e, NT - 1), ly = i / (LSS_TX + 2), lx = i - ly * (LSS_TX + 2);
+            const size_t o = (size_t)clampi(by - 1 + ly, 0, H - 1) * W + clampi(bx - 1 + lx, 0, W - 1);
+            p1[e] = im1[o]; p2[e] = im2[o];
+        }
+#pragma unroll
+        for (int e = 0; e < NLD; ++e) {
+            const int i = tid + 256 * e, ly = i / (LSS_TX + 2), lx = i - ly * (LSS_TX + 2);
+            if (i < NT) { t1[ly][lx] = __fdiv_rn(p1[e], m1); t2[ly][lx] = __fdiv_rn(p2[e], m2); }
+        }
+    }
+    __syncthreads();
+    int x = bx + threadIdx.x;
+    int y = by + threadIdx.y;
+    if (x >= W || y >= H) return;
     int ym = clampi(y - 1, 0, H - 1), yp = clampi(y + 1, 0, H - 1);
     int xm = clampi(x - 1, 0, W - 1), xp = clampi(x + 1, 0, W - 1);
-    auto n1 = [&](int yy, int xx) { return __fdiv_rn(im1[(size_t)yy * W + xx], m1); };
-    auto n2 = [&](int yy, int xx) { return __fdiv_rn(im2[(size_t)yy * W + xx], m2); };
+    auto n1 = [&](int yy, int xx) { return t1[yy - by + 1][xx - bx + 1]; };
+    auto n2 = [&](int yy, int xx) { return t2[yy - by + 1][xx - bx + 1]; };
     const float c = n1(y, x), up = n1(ym, x), dn = n1(yp, x), lf = n1(y, xm), rt = n1(y, xp);
     // (im2-im1)/dt - f with dt=1, f=0 at the four neighbours
     const float tu = __fsub_rn(n2(ym, x), up), td = __fsub_rn(n2(yp, x), dn), tl = __fsub_rn(n2(y, xm), lf), tr = __fsub_rn(n2(y, xp), rt);
@@ -696,7 +733,7 @@ extern "C" int ofri_ls_compute(ofri_ctx *ctx, const float *im1, const float *im2
         if (gm > LS_MAX_PARTS) gm = LS_MAX_PARTS;
         k_ls_max2<<<gm, 256, 0, ctx->stream>>>(im1, im2, n, mx.as<float>());
         OFRI_LAUNCH_CHECK();
-        dim3 bs(64, 4), gs(ceil_div(cols, 64), ceil_div(rows, 4));
+        dim3 bs(LSS_TX, LSS_TY), gs(ceil_div(cols, LSS_TX), ceil_div(rows, LSS_TY));
         if (exact) k_ls_setup<true><<<gs, bs, 0, ctx->stream>>>(im1, im2, mx.as<float>(), gm, h, P, n, rows, cols, state, first_src);
         else k_ls_setup<false><<<gs, bs, 0, ctx->stream>>>(im1, im2, mx.as<float>(), gm, h, P, n, rows, cols, state, first_src);
         OFRI_LAUNCH_CHECK();
