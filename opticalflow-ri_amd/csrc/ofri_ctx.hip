@@ -316,17 +316,25 @@ extern "C" int ofri_event_destroy(ofri_event *ev) {
 template <class T>
 __global__ void k_to_f32(const T *__restrict__ s, float *__restrict__ d, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, st = (size_t)gridDim.x * blockDim.x;
+    if ((((size_t)s) & (4 * sizeof(T) - 1)) == 0 && (((size_t)d) & 15) == 0) {       // four samples per load, 16-byte stores
+        typedef T T4 __attribute__((ext_vector_type(4)));
+        const T4 *s4 = reinterpret_cast<const T4 *>(s);
+        float4 *d4 = reinterpret_cast<float4 *>(d);
+        const size_t n4 = n / 4;
+        for (; i < n4; i += st) { const T4 v = s4[i]; d4[i] = make_float4((float)v.x, (float)v.y, (float)v.z, (float)v.w); }
+        i = 4 * n4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    }
     for (; i < n; i += st) d[i] = (float)s[i];
 }
-static int grid_for(size_t n, int block) {
-    size_t g = (n + block - 1) / block;
+static int grid_for(size_t n, int block, int per_thread = 1) {        // per_thread: elements a thread takes per round
+    size_t g = (n / per_thread + block - 1) / block;
     return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
 }
 extern "C" int ofri_u8_to_f32(ofri_ctx *ctx, const unsigned char *src, float *dst, size_t n) {
     OFRI_TRY(ofri_check_ctx(ctx));
     OFRI_REQUIRE(src && dst, "null pointer");
     if (!n) return OFRI_OK;
-    k_to_f32<unsigned char><<<grid_for(n, 256), 256, 0, ctx->stream>>>(src, dst, n);
+    k_to_f32<unsigned char><<<grid_for(n, 256, 4), 256, 0, ctx->stream>>>(src, dst, n);
     OFRI_LAUNCH_CHECK();
     return OFRI_OK;
 }
@@ -334,7 +342,7 @@ extern "C" int ofri_u16_to_f32(ofri_ctx *ctx, const unsigned short *src, float *
     OFRI_TRY(ofri_check_ctx(ctx));
     OFRI_REQUIRE(src && dst, "null pointer");
     if (!n) return OFRI_OK;
-    k_to_f32<unsigned short><<<grid_for(n, 256), 256, 0, ctx->stream>>>(src, dst, n);
+    k_to_f32<unsigned short><<<grid_for(n, 256, 4), 256, 0, ctx->stream>>>(src, dst, n);
     OFRI_LAUNCH_CHECK();
     return OFRI_OK;
 }
@@ -352,17 +360,33 @@ __global__ void k_range_rule(float *__restrict__ a, float *__restrict__ b, size_
 
 __global__ void k_add_inplace(float *__restrict__ acc, const float *__restrict__ x, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, st = (size_t)gridDim.x * blockDim.x;
+    if (((((size_t)acc) | ((size_t)x)) & 15) == 0) {
+        float4 *a4 = reinterpret_cast<float4 *>(acc);
+        const float4 *x4 = reinterpret_cast<const float4 *>(x);
+        const size_t n4 = n / 4;
+        for (; i < n4; i += st) {
+            const float4 p = a4[i], q = x4[i];
+            a4[i] = make_float4(__fadd_rn(p.x, q.x), __fadd_rn(p.y, q.y), __fadd_rn(p.z, q.z), __fadd_rn(p.w, q.w));
+        }
+        i = 4 * n4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    }
     for (; i < n; i += st) acc[i] = acc[i] + x[i];
 }
 __global__ void k_scale_inplace(float *__restrict__ y, float s, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, st = (size_t)gridDim.x * blockDim.x;
+    if ((((size_t)y) & 15) == 0) {
+        float4 *y4 = reinterpret_cast<float4 *>(y);
+        const size_t n4 = n / 4;
+        for (; i < n4; i += st) { const float4 p = y4[i]; y4[i] = make_float4(__fmul_rn(p.x, s), __fmul_rn(p.y, s), __fmul_rn(p.z, s), __fmul_rn(p.w, s)); }
+        i = 4 * n4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    }
     for (; i < n; i += st) y[i] = y[i] * s;
 }
 extern "C" int ofri_add_inplace(ofri_ctx *ctx, float *acc, const float *x, size_t n) {
     OFRI_TRY(ofri_check_ctx(ctx));
     OFRI_REQUIRE(acc && x, "null pointer");
     if (!n) return OFRI_OK;
-    k_add_inplace<<<grid_for(n, 256), 256, 0, ctx->stream>>>(acc, x, n);
+    k_add_inplace<<<grid_for(n, 256, 4), 256, 0, ctx->stream>>>(acc, x, n);
     OFRI_LAUNCH_CHECK();
     return OFRI_OK;
 }
@@ -370,7 +394,7 @@ extern "C" int ofri_scale_inplace(ofri_ctx *ctx, float *y, float s, size_t n) {
     OFRI_TRY(ofri_check_ctx(ctx));
     OFRI_REQUIRE(y, "null pointer");
     if (!n) return OFRI_OK;
-    k_scale_inplace<<<grid_for(n, 256), 256, 0, ctx->stream>>>(y, s, n);
+    k_scale_inplace<<<grid_for(n, 256, 4), 256, 0, ctx->stream>>>(y, s, n);
     OFRI_LAUNCH_CHECK();
     return OFRI_OK;
 }
