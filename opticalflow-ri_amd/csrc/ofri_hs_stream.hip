@@ -71,6 +71,50 @@ extern "C" int ofri_debug_sl_trace_clear(void) {
     return hipMemset(p, 0, sizeof(unsigned long long) * 3 * SL_TRACE_MAX) == hipSuccess ? 0 : 1;
 }
 #endif
+// SIMD (0..3) of the CU that the calling wavefront runs on
+__device__ __forceinline__ int sl_simd_id() {
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    return (hw >> 4) & 3;
+}
+// Which wavefronts of a workgroup load and which compute.  A stage wavefront issues about 120 vector instructions per
+// step and a loader next to none, and a step ends when the busiest SIMD is done.  The hardware deals a workgroup's
+// wavefronts over the SIMDs in the order 0 2 1 3 from wherever the workgroup before it on that CU stopped, so with
+// fixed roles two workgroups of 6 + 2 wavefronts often put their loaders on the same SIMDs: 4 stage wavefronts on one
+// SIMD and 2 on another, and a step takes the time of four.  The roles are therefore dealt at run time.  A loader goes
+// to the SIMD that holds most of this workgroup's wavefronts (five wavefronts: the SIMD with two, which leaves one
+// stage wavefront per SIMD); among equals to the SIMD this workgroup's dispatch round prefers (round = blockIdx / CUs:
+// the workgroups that share a CU come from different rounds, so their loaders end up on different SIMDs and the
+// stage wavefronts three per SIMD).  Returns the wavefront's role: 0 .. NW - NLW - 1 stages in wavefront order,
+// NW - NLW .. NW - 1 loaders.  Any placement gives a valid set of roles; only the balance depends on it.
+template <int NW, int NLW>
+__device__ __forceinline__ int sl_wave_role(int *wave_simd, int round) {
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x / 64);
+    if ((threadIdx.x & 63) == 0) wave_simd[w] = sl_simd_id();
+    __syncthreads();
+    unsigned cnt = 0;                              // wavefronts of this workgroup per SIMD, a byte each
+    for (int i = 0; i < NW; ++i) cnt += 1u << (8 * wave_simd[i]);
+    int pick0 = -1, pick1 = -1;
+    for (int k = 0; k < NLW; ++k) {
+        unsigned mx = 0;
+        for (int q = 0; q < 4; ++q) mx = max(mx, (cnt >> (8 * q)) & 255u);
+        const int start = NLW == 2 ? 2 * (round & 1) + k : (round & 3);
+        int sd = start & 3;
+        for (int j = 3; j >= 0; --j) {
+            const int q = (start + j) & 3;
+            if (((cnt >> (8 * q)) & 255u) == mx) sd = q;
+        }
+        int pk = -1;
+        for (int i = 0; i < NW; ++i)
+            if (wave_simd[i] == sd && i != pick0) pk = i;          // the last such wavefront
+        if (pk < 0) pk = pick0 == NW - 1 ? NW - 2 : NW - 1;        // cannot happen; keeps the roles a permutation
+        if (k == 0) pick0 = pk; else pick1 = pk;
+        cnt -= 1u << (8 * sd);
+    }
+    if (w == pick0) return NW - NLW;
+    if (NLW == 2 && w == pick1) return NW - 1;
+    return w - (pick0 < w ? 1 : 0) - (NLW == 2 && pick1 < w ? 1 : 0);
+}
 struct SlPlanes { const float *U, *V, *fx, *fy, *ft; };        // dense planes (fx, fy, ft: scaled A, B, C); V, fy one plane after U, fx
 struct SlRow { float u[4], v[4]; };                            // a lane's four pixels of one row
 struct SlCoef { float4 fx, fy, ft; };
@@ -119,7 +163,8 @@ template <int NL, int LN, bool FULL, bool ACC, bool LASTW>
 __device__ __forceinline__ void sl_stage_step(SlStage &st, float4 (&ring)[SlCfg<NL, LN>::NS][2][2][LN],
                                               float4 (&coef)[SlCfg<NL, LN>::CR][3][LN], int stage, int l, bool passA, bool passB,
                                               bool store_lane, int lane_off, float *__restrict__ rowU, float *__restrict__ rowV,
-                                              bool row_ok, const float *__restrict__ accU, const float *__restrict__ accV, int lane_safe) {
+                                              bool row_ok, const float *__restrict__ accU, const float *__restrict__ accV, int lane_safe,
+                                              bool idle) {
     constexpr int SL_NS = SlCfg<NL, LN>::NS, SL_CR = SlCfg<NL, LN>::CR;
     // newest input row rA+1, written one step ago
     const float4 nu4 = ring[stage][(st.rA + 1) & 1][0][l], nv4 = ring[stage][(st.rA + 1) & 1][1][l];
@@ -130,9 +175,10 @@ __device__ __forceinline__ void sl_stage_step(SlStage &st, float4 (&ring)[SlCfg<
     nw.u[0] = nu4.x; nw.u[1] = nu4.y; nw.u[2] = nu4.z; nw.u[3] = nu4.w;
     nw.v[0] = nv4.x; nw.v[1] = nv4.y; nw.v[2] = nv4.z; nw.v[3] = nv4.w;
     SlRow mid2, out;
-    if (!FULL && __builtin_amdgcn_ballot_w64(!(passA && passB)) == 0) {
-        // neither stage of this wavefront has a sweep to do (fewer sweeps asked than the pipeline is deep):
-        // hand the rows on untouched
+    if (idle || (!FULL && __builtin_amdgcn_ballot_w64(!(passA && passB)) == 0)) {
+        // idle: the rows this wavefront's stages would make at this step are outside what the chunk's result depends on
+        // (the pipeline is filling or draining); or neither stage of this wavefront has a sweep to do (fewer sweeps asked
+        // than the pipeline is deep): hand the rows on untouched
         mid2 = st.in1;
         out = st.mid1;
     } else {
@@ -238,9 +284,13 @@ k_hs_stream(SlPlanes in, float *__restrict__ Uo, float *__restrict__ Vo, int H, 
     constexpr int SL_RX = SlCfg<NL, LN>::RX;
     __shared__ float4 ring[SL_NS][2][2][LN];      // ring[s]: input rows of stage s.  [row & 1][U|V][lane]
     __shared__ float4 coef[SL_CR][3][LN];         // [row slot][A|B|C][lane]
-    const int tid = threadIdx.x;
+    constexpr int SL_NW = SlCfg<NL, LN>::THREADS / 64, SL_NLW = 2 * LN / 64;
+    static_assert(SlCfg<NL, LN>::THREADS % 64 == 0, "whole wavefronts");
+    __shared__ int wave_simd[SL_NW];
+    // thread index by role: stages first, then the loader (sl_wave_role)
+    const int tid = sl_wave_role<SL_NW, SL_NLW>(wave_simd, pr.ncu > 0 ? blockIdx.x / pr.ncu : 0) * 64 + (threadIdx.x & 63);
 #ifdef OFRI_SL_TRACE
-    if (tid == 0 && blockIdx.x < SL_TRACE_MAX) {
+    if (threadIdx.x == 0 && blockIdx.x < SL_TRACE_MAX) {
         g_sl_trace[3 * blockIdx.x] = wall_clock64();
         unsigned hw, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
@@ -292,13 +342,21 @@ k_hs_stream(SlPlanes in, float *__restrict__ Uo, float *__restrict__ Vo, int H, 
         const int lane_safe = min(max(lane_off, 0), W - 4);
         // the wavefront that holds the last stage (it alone touches the destination)
         const bool lastw = __builtin_amdgcn_readfirstlane(tid / 64) == (SL_NS * LN - 1) / 64;
+        // Steps at which this wavefront's stages have nothing to contribute.  Sweep k of a chunk is needed on rows
+        // ya - (NL - k) .. yb - 1 + (NL - k) only; stage s makes row rA = rho0 - 2 - 3 s + t of sweep 2 s + 1 and row rA - 1 of
+        // sweep 2 s + 2 at step t, so it is needed for 5 s + 3 <= t <= (yb - ya) + 2 NL + s.  Outside that window (the
+        // pipeline's fill and drain) the wavefront skips the arithmetic and leaves the issue slots to the other
+        // workgroups of the CU; what it hands on then is never used.
+        const int wv = __builtin_amdgcn_readfirstlane(tid / 64);
+        const int w_lo = 5 * ((wv * 64) / LN) + 3, w_hi = (yb - ya) + 2 * SL_NL + (wv * 64 + 63) / LN;
         // six steps per round (NS is a multiple): the row registers rotate by renaming instead of moves
 #define SL_STEP(U_, LASTW_)                                                                                           \
     {                                                                                                                 \
         const int ro = rho0 - SL_LAG + t + (U_);          /* row the last stage finishes at this step */              \
         const long long ra = (long long)min(max(ro + 3, ya), yb - 1) * W;      /* row whose old values are fetched */  \
+        const bool idle = t + (U_) < w_lo || t + (U_) > w_hi;                                                         \
         sl_stage_step<NL, LN, FULL, ACC, LASTW_>(st, ring, coef, stage, l, passA, passB, store_lane, lane_off, Uo + (long long)ro * W, \
-                                     Vo + (long long)ro * W, ro >= ya && ro < yb, Uo + ra, Vo + ra, lane_safe);        \
+                                     Vo + (long long)ro * W, ro >= ya && ro < yb, Uo + ra, Vo + ra, lane_safe, idle);  \
         __syncthreads();                                                                                              \
     }
         OfriPrioState ps = ofri_prio_begin(pr, NS, blockIdx.x);

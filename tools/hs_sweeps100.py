@@ -2,7 +2,7 @@
 """A level's Horn-Schunck sweep loop (96 and 100 sweeps) under every launch shape."""
 import os, sys
 import numpy as np
-ROOT = "/root/repo"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "opticalflow-ri_amd")]
 import _ofri
 if len(sys.argv) > 1:
@@ -12,7 +12,7 @@ ctx = _ofri.Context(0); lib = _ofri.lib()
 for n in SIZES:
     rng = np.random.default_rng(0)
     pl = [ctx.upload(rng.standard_normal((n, n)).astype(np.float32)) for _ in range(5)]
-    for fuse in (16, 0, 32, 0, 8, 16):
+    for fuse in (16, 0, 32, 0, 32, 16):
         for T in (96, 100):
             ctx.set_hs_fuse(fuse)
             def run():
