@@ -116,31 +116,50 @@ __device__ __forceinline__ int sl_wave_role(int *wave_simd, int round) {
     return w - (pick0 < w ? 1 : 0) - (NLW == 2 && pick1 < w ? 1 : 0);
 }
 struct SlPlanes { const float *U, *V, *fx, *fy, *ft; };        // dense planes (fx, fy, ft: scaled A, B, C); V, fy one plane after U, fx
-struct SlRow { float u[4], v[4]; };                            // a lane's four pixels of one row
-struct SlCoef { float4 fx, fy, ft; };
+// Packed arithmetic.  On gfx950 a v_fma_f32 (64-bit encoding) issues once per 4.3 cycles per SIMD however many wavefronts
+// share it, and so does a v_pk_fma_f32, which does two (tools/valu_operands.hip); only plain 32-bit encoded v_add / v_mul /
+// v_fmac reach 2.5.  The u and v of a pixel go through the same averaging arithmetic, so a pixel's (u, v) is kept as one
+// register pair and every step of the average and the final update is one packed instruction for both; the data term
+// der = A ubar + B vbar + C mixes the two and stays scalar.  Same operations on the same values as ofri_hs_math.h, so
+// the bits are those of the other Horn-Schunck kernels.
+typedef float f2 __attribute__((ext_vector_type(2)));
+struct SlRow { f2 p[4]; };                                     // (u, v) of a lane's four pixels of one row
+struct SlCoef { f2 ab[4]; float c[4]; };                       // (A, B) and C of a lane's four pixels
+__device__ __forceinline__ f2 sl_left2(f2 v) { return (f2){sl_left(v.x), sl_left(v.y)}; }
+__device__ __forceinline__ f2 sl_right2(f2 v) { return (f2){sl_right(v.x), sl_right(v.y)}; }
+__device__ __forceinline__ f2 sl_pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 sl_pk_add(f2 a, f2 b) {
+    f2 r;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f2 sl_pk_mul(f2 a, f2 b) {
+    f2 r;
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ void sl_unpack(const float4 &lo, const float4 &hi, f2 (&p)[4]) {
+    p[0] = (f2){lo.x, lo.y}; p[1] = (f2){lo.z, lo.w}; p[2] = (f2){hi.x, hi.y}; p[3] = (f2){hi.z, hi.w};
+}
 
 // one sweep of a row: a = row above, c = the row, b = row below; pass (only when !FULL) = copy the row instead
 template <bool FULL>
-__device__ __forceinline__ SlRow sl_sweep(const SlRow &a, const SlRow &c, const SlRow &b, const SlCoef &g, bool pass) {
-    const float gx[4] = {g.fx.x, g.fx.y, g.fx.z, g.fx.w}, gy[4] = {g.fy.x, g.fy.y, g.fy.z, g.fy.w};
-    const float gt[4] = {g.ft.x, g.ft.y, g.ft.z, g.ft.w};
-    float su[4], sv[4], qu[6], qv[6];
+__device__ __forceinline__ SlRow sl_sweep(const SlRow &a, const SlRow &c, const SlRow &b, const SlCoef &g, bool pass, f2 w12) {
+    const f2 two = {2.0f, 2.0f};
+    f2 s[4], q[6];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        su[k] = __fadd_rn(a.u[k], b.u[k]); sv[k] = __fadd_rn(a.v[k], b.v[k]);
-        qu[k + 1] = hs_q(c.u[k], su[k]); qv[k + 1] = hs_q(c.v[k], sv[k]);
+        s[k] = sl_pk_add(a.p[k], b.p[k]);                      // hs_avg's s: vertical pair sum
+        q[k + 1] = sl_pk_fma(two, c.p[k], s[k]);               // hs_q
     }
-    qu[0] = sl_left(qu[4]); qu[5] = sl_right(qu[1]);
-    qv[0] = sl_left(qv[4]); qv[5] = sl_right(qv[1]);
+    q[0] = sl_left2(q[4]); q[5] = sl_right2(q[1]);
     SlRow o;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        // the neighbour lane's value goes first (a + b == b + a exactly): as first operand the lane shift folds into the add
-        const int p = k == 3 ? k + 2 : k, q = k == 3 ? k : k + 2;
-        float ua = hs_avg(su[k], qu[p], qu[q]);
-        float va = hs_avg(sv[k], qv[p], qv[q]);
-        hs_update(ua, va, gx[k], gy[k], gt[k], o.u[k], o.v[k]);
-        if (!FULL && pass) { o.u[k] = c.u[k]; o.v[k] = c.v[k]; }
+        const f2 av = sl_pk_mul(sl_pk_fma(two, s[k], sl_pk_add(q[k], q[k + 2])), w12);        // hs_avg
+        const float der = fmaf(g.ab[k].x, av.x, fmaf(g.ab[k].y, av.y, g.c[k]));                // hs_update
+        o.p[k] = sl_pk_fma(-g.ab[k], (f2){der, der}, av);
+        if (!FULL && pass) o.p[k] = c.p[k];
     }
     return o;
 }
@@ -164,16 +183,20 @@ __device__ __forceinline__ void sl_stage_step(SlStage &st, float4 (&ring)[SlCfg<
                                               float4 (&coef)[SlCfg<NL, LN>::CR][3][LN], int stage, int l, bool passA, bool passB,
                                               bool store_lane, int lane_off, float *__restrict__ rowU, float *__restrict__ rowV,
                                               bool row_ok, const float *__restrict__ accU, const float *__restrict__ accV, int lane_safe,
-                                              bool idle) {
+                                              bool idle, f2 w12) {
     constexpr int SL_NS = SlCfg<NL, LN>::NS, SL_CR = SlCfg<NL, LN>::CR;
     // newest input row rA+1, written one step ago
-    const float4 nu4 = ring[stage][(st.rA + 1) & 1][0][l], nv4 = ring[stage][(st.rA + 1) & 1][1][l];
+    // ring and coefficient rows hold a lane's pixels interleaved: [0] = u0 v0 u1 v1 (A0 B0 A1 B1), [1] = u2 v2 u3 v3
+    const float4 n01 = ring[stage][(st.rA + 1) & 1][0][l], n23 = ring[stage][(st.rA + 1) & 1][1][l];
     SlCoef g;
-    g.fx = coef[st.cslot][0][l]; g.fy = coef[st.cslot][1][l]; g.ft = coef[st.cslot][2][l];
+    {
+        const float4 g01 = coef[st.cslot][0][l], g23 = coef[st.cslot][1][l], gc = coef[st.cslot][2][l];
+        sl_unpack(g01, g23, g.ab);
+        g.c[0] = gc.x; g.c[1] = gc.y; g.c[2] = gc.z; g.c[3] = gc.w;
+    }
     st.cslot = st.cslot + 1 == SL_CR ? 0 : st.cslot + 1;
     SlRow nw;
-    nw.u[0] = nu4.x; nw.u[1] = nu4.y; nw.u[2] = nu4.z; nw.u[3] = nu4.w;
-    nw.v[0] = nv4.x; nw.v[1] = nv4.y; nw.v[2] = nv4.z; nw.v[3] = nv4.w;
+    sl_unpack(n01, n23, nw.p);
     SlRow mid2, out;
     if (idle || (!FULL && __builtin_amdgcn_ballot_w64(!(passA && passB)) == 0)) {
         // idle: the rows this wavefront's stages would make at this step are outside what the chunk's result depends on
@@ -182,8 +205,8 @@ __device__ __forceinline__ void sl_stage_step(SlStage &st, float4 (&ring)[SlCfg<
         mid2 = st.in1;
         out = st.mid1;
     } else {
-        mid2 = sl_sweep<FULL>(st.in0, st.in1, nw, g, passA);                   // row rA of the first sweep
-        out = sl_sweep<FULL>(st.mid0, st.mid1, mid2, st.gprev, passB);         // row rA-1 of the second sweep
+        mid2 = sl_sweep<FULL>(st.in0, st.in1, nw, g, passA, w12);              // row rA of the first sweep
+        out = sl_sweep<FULL>(st.mid0, st.mid1, mid2, st.gprev, passB, w12);    // row rA-1 of the second sweep
     }
     const int rB = st.rA - 1;
     float4 a0u, a0v;
@@ -194,10 +217,10 @@ __device__ __forceinline__ void sl_stage_step(SlStage &st, float4 (&ring)[SlCfg<
         st.av2 = *reinterpret_cast<const float4 *>(accV + lane_safe);
     }
     if (stage < SL_NS - 1) {
-        ring[stage + 1][rB & 1][0][l] = make_float4(out.u[0], out.u[1], out.u[2], out.u[3]);
-        ring[stage + 1][rB & 1][1][l] = make_float4(out.v[0], out.v[1], out.v[2], out.v[3]);
+        ring[stage + 1][rB & 1][0][l] = make_float4(out.p[0].x, out.p[0].y, out.p[1].x, out.p[1].y);
+        ring[stage + 1][rB & 1][1][l] = make_float4(out.p[2].x, out.p[2].y, out.p[3].x, out.p[3].y);
     } else {
-        float4 ou = make_float4(out.u[0], out.u[1], out.u[2], out.u[3]), ov = make_float4(out.v[0], out.v[1], out.v[2], out.v[3]);
+        float4 ou = make_float4(out.p[0].x, out.p[1].x, out.p[2].x, out.p[3].x), ov = make_float4(out.p[0].y, out.p[1].y, out.p[2].y, out.p[3].y);
         if (ACC && LASTW) {
             ou = make_float4(__fadd_rn(a0u.x, ou.x), __fadd_rn(a0u.y, ou.y), __fadd_rn(a0u.z, ou.z), __fadd_rn(a0u.w, ou.w));
             ov = make_float4(__fadd_rn(a0v.x, ov.x), __fadd_rn(a0v.y, ov.y), __fadd_rn(a0v.z, ov.z), __fadd_rn(a0v.w, ov.w));
@@ -257,8 +280,13 @@ __device__ __forceinline__ void sl_loader(const SlPlanes &in, float4 (&ring)[SlC
 #define SL_STEP(U_)                                                                \
     {                                                                              \
         const int rho = rho0 + t0 + (U_);                                          \
-        ring[0][rho & 1][lset][lj] = qa##U_;                                       \
-        coef[lslot][lset][lj] = qb##U_;                                            \
+        /* interleaved rows: set 0 (U, A) fills the even floats of [0] and [1], set 1 (V, B) the odd ones */ \
+        {                                                                          \
+            float *r0 = reinterpret_cast<float *>(&ring[0][rho & 1][0][lj]) + lset, *r1 = reinterpret_cast<float *>(&ring[0][rho & 1][1][lj]) + lset; \
+            float *c0 = reinterpret_cast<float *>(&coef[lslot][0][lj]) + lset, *c1 = reinterpret_cast<float *>(&coef[lslot][1][lj]) + lset; \
+            r0[0] = qa##U_.x; r0[2] = qa##U_.y; r1[0] = qa##U_.z; r1[2] = qa##U_.w; \
+            c0[0] = qb##U_.x; c0[2] = qb##U_.y; c1[0] = qb##U_.z; c1[2] = qb##U_.w; \
+        }                                                                          \
         if (!lset) coef[lslot][2][lj] = qc##U_;                                    \
         lslot = lslot + 1 == SL_CR ? 0 : lslot + 1;                                \
         SL_LOAD(U_, rho + SL_PF)                                                   \
@@ -329,10 +357,13 @@ k_hs_stream(SlPlanes in, float *__restrict__ Uo, float *__restrict__ Vo, int H, 
         SlStage st;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            st.in0.u[k] = st.in0.v[k] = st.in1.u[k] = st.in1.v[k] = 0.f;
-            st.mid0.u[k] = st.mid0.v[k] = st.mid1.u[k] = st.mid1.v[k] = 0.f;
+            st.in0.p[k] = st.in1.p[k] = st.mid0.p[k] = st.mid1.p[k] = st.gprev.ab[k] = (f2){0.f, 0.f};
+            st.gprev.c[k] = 0.f;
         }
-        st.gprev.fx = st.gprev.fy = st.gprev.ft = make_float4(0.f, 0.f, 0.f, 0.f);
+        // 1/12 for both halves of the packed multiply, in scalar registers (a packed instruction takes no literal)
+        f2 w12;
+        asm volatile("s_mov_b32 %0, 0x3daaaaab" : "=s"(w12.x));
+        asm volatile("s_mov_b32 %0, 0x3daaaaab" : "=s"(w12.y));
         st.au0 = st.av0 = st.au1 = st.av1 = st.au2 = st.av2 = make_float4(0.f, 0.f, 0.f, 0.f);
         st.rA = rho0 - 2 - 3 * stage;
         st.cslot = (st.rA + 64 * SL_CR) % SL_CR;
@@ -356,7 +387,7 @@ k_hs_stream(SlPlanes in, float *__restrict__ Uo, float *__restrict__ Vo, int H, 
         const long long ra = (long long)min(max(ro + 3, ya), yb - 1) * W;      /* row whose old values are fetched */  \
         const bool idle = t + (U_) < w_lo || t + (U_) > w_hi;                                                         \
         sl_stage_step<NL, LN, FULL, ACC, LASTW_>(st, ring, coef, stage, l, passA, passB, store_lane, lane_off, Uo + (long long)ro * W, \
-                                     Vo + (long long)ro * W, ro >= ya && ro < yb, Uo + ra, Vo + ra, lane_safe, idle);  \
+                                     Vo + (long long)ro * W, ro >= ya && ro < yb, Uo + ra, Vo + ra, lane_safe, idle, w12); \
         __syncthreads();                                                                                              \
     }
         OfriPrioState ps = ofri_prio_begin(pr, NS, blockIdx.x);
