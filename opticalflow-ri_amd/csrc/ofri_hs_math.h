@@ -29,6 +29,35 @@ __device__ __forceinline__ void hs_update(float ua, float va, float A, float B, 
     vn = fmaf(-B, der, va);
 }
 
+// ---- packed form ----------------------------------------------------------------------------------------
+// On gfx950 a v_fma_f32 (64-bit encoding) issues once per 4.3 cycles per SIMD however many wavefronts share it, and so
+// does a v_pk_fma_f32, which does two; only plain 32-bit encoded v_add / v_mul / v_fmac reach 2.5
+// (tools/valu_operands.hip).  The u and v of a pixel go through the same averaging arithmetic, so the blocked kernels
+// keep a pixel's (u, v) as one register pair: every step of the average and the final update is one packed
+// instruction for both; the data term der = A ubar + B vbar + C mixes the two and stays scalar.  Same operations on
+// the same values as the scalar functions above, so the bits are the same.
+typedef float hs_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ hs_f2 hs_pk_fma(hs_f2 a, hs_f2 b, hs_f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ hs_f2 hs_pk_add(hs_f2 a, hs_f2 b) { return a + b; }
+__device__ __forceinline__ hs_f2 hs_pk_mul(hs_f2 a, hs_f2 b) { return a * b; }
+// float32(1/12) in both halves of a pair, from scalar registers (a packed instruction takes no literal)
+__device__ __forceinline__ hs_f2 hs_w12_pair() {
+    hs_f2 w;
+    asm volatile("s_mov_b32 %0, 0x3daaaaab" : "=s"(w.x));
+    asm volatile("s_mov_b32 %0, 0x3daaaaab" : "=s"(w.y));
+    return w;
+}
+// s = vertical pair sum of the pixel's column (hs_avg's s), c = the pixel itself: q = 2 c + s
+__device__ __forceinline__ hs_f2 hs_q_pk(hs_f2 c, hs_f2 s) { return hs_pk_fma((hs_f2){2.0f, 2.0f}, c, s); }
+// the new (u, v) of a pixel from its s, the q of its left and right columns, its coefficients (A, B) and C
+__device__ __forceinline__ hs_f2 hs_step_pk(hs_f2 s, hs_f2 q_a, hs_f2 q_b, hs_f2 ab, float c, hs_f2 w12) {
+    const hs_f2 av = hs_pk_mul(hs_pk_fma((hs_f2){2.0f, 2.0f}, s, hs_pk_add(q_a, q_b)), w12);      // hs_avg
+    const float der = fmaf(ab.x, av.x, fmaf(ab.y, av.y, c));                                       // hs_update
+    // the sign goes on der (a fresh value: a source modifier), not on the coefficients, which a compiler would negate
+    // once outside a sweep loop at the cost of a second set of registers; fma(-A, der, ubar) == fma(A, -der, ubar)
+    return hs_pk_fma(ab, -(hs_f2){der, der}, av);
+}
+
 // The derivative cube at pixel (y, x) (reference computeDerivatives, src/HornSchunck.py:107-127).
 // scipy.ndimage.convolve with a 2x2 kernel w and 'mirror' border evaluates
 //   out[i,j] = w11*in[i,j] + w10*in[i,j+1] + w01*in[i+1,j] + w00*in[i+1,j+1]

@@ -116,28 +116,12 @@ __device__ __forceinline__ int sl_wave_role(int *wave_simd, int round) {
     return w - (pick0 < w ? 1 : 0) - (NLW == 2 && pick1 < w ? 1 : 0);
 }
 struct SlPlanes { const float *U, *V, *fx, *fy, *ft; };        // dense planes (fx, fy, ft: scaled A, B, C); V, fy one plane after U, fx
-// Packed arithmetic.  On gfx950 a v_fma_f32 (64-bit encoding) issues once per 4.3 cycles per SIMD however many wavefronts
-// share it, and so does a v_pk_fma_f32, which does two (tools/valu_operands.hip); only plain 32-bit encoded v_add / v_mul /
-// v_fmac reach 2.5.  The u and v of a pixel go through the same averaging arithmetic, so a pixel's (u, v) is kept as one
-// register pair and every step of the average and the final update is one packed instruction for both; the data term
-// der = A ubar + B vbar + C mixes the two and stays scalar.  Same operations on the same values as ofri_hs_math.h, so
-// the bits are those of the other Horn-Schunck kernels.
-typedef float f2 __attribute__((ext_vector_type(2)));
+// A pixel's (u, v) is one register pair and the sweeps run in the packed arithmetic of ofri_hs_math.h.
+typedef hs_f2 f2;
 struct SlRow { f2 p[4]; };                                     // (u, v) of a lane's four pixels of one row
 struct SlCoef { f2 ab[4]; float c[4]; };                       // (A, B) and C of a lane's four pixels
 __device__ __forceinline__ f2 sl_left2(f2 v) { return (f2){sl_left(v.x), sl_left(v.y)}; }
 __device__ __forceinline__ f2 sl_right2(f2 v) { return (f2){sl_right(v.x), sl_right(v.y)}; }
-__device__ __forceinline__ f2 sl_pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ f2 sl_pk_add(f2 a, f2 b) {
-    f2 r;
-    asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ f2 sl_pk_mul(f2 a, f2 b) {
-    f2 r;
-    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
 __device__ __forceinline__ void sl_unpack(const float4 &lo, const float4 &hi, f2 (&p)[4]) {
     p[0] = (f2){lo.x, lo.y}; p[1] = (f2){lo.z, lo.w}; p[2] = (f2){hi.x, hi.y}; p[3] = (f2){hi.z, hi.w};
 }
@@ -145,20 +129,17 @@ __device__ __forceinline__ void sl_unpack(const float4 &lo, const float4 &hi, f2
 // one sweep of a row: a = row above, c = the row, b = row below; pass (only when !FULL) = copy the row instead
 template <bool FULL>
 __device__ __forceinline__ SlRow sl_sweep(const SlRow &a, const SlRow &c, const SlRow &b, const SlCoef &g, bool pass, f2 w12) {
-    const f2 two = {2.0f, 2.0f};
     f2 s[4], q[6];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        s[k] = sl_pk_add(a.p[k], b.p[k]);                      // hs_avg's s: vertical pair sum
-        q[k + 1] = sl_pk_fma(two, c.p[k], s[k]);               // hs_q
+        s[k] = hs_pk_add(a.p[k], b.p[k]);                      // vertical pair sum
+        q[k + 1] = hs_q_pk(c.p[k], s[k]);
     }
     q[0] = sl_left2(q[4]); q[5] = sl_right2(q[1]);
     SlRow o;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const f2 av = sl_pk_mul(sl_pk_fma(two, s[k], sl_pk_add(q[k], q[k + 2])), w12);        // hs_avg
-        const float der = fmaf(g.ab[k].x, av.x, fmaf(g.ab[k].y, av.y, g.c[k]));                // hs_update
-        o.p[k] = sl_pk_fma(-g.ab[k], (f2){der, der}, av);
+        o.p[k] = hs_step_pk(s[k], q[k], q[k + 2], g.ab[k], g.c[k], w12);
         if (!FULL && pass) o.p[k] = c.p[k];
     }
     return o;
@@ -360,10 +341,7 @@ k_hs_stream(SlPlanes in, float *__restrict__ Uo, float *__restrict__ Vo, int H, 
             st.in0.p[k] = st.in1.p[k] = st.mid0.p[k] = st.mid1.p[k] = st.gprev.ab[k] = (f2){0.f, 0.f};
             st.gprev.c[k] = 0.f;
         }
-        // 1/12 for both halves of the packed multiply, in scalar registers (a packed instruction takes no literal)
-        f2 w12;
-        asm volatile("s_mov_b32 %0, 0x3daaaaab" : "=s"(w12.x));
-        asm volatile("s_mov_b32 %0, 0x3daaaaab" : "=s"(w12.y));
+        const f2 w12 = hs_w12_pair();
         st.au0 = st.av0 = st.au1 = st.av1 = st.au2 = st.av2 = make_float4(0.f, 0.f, 0.f, 0.f);
         st.rA = rho0 - 2 - 3 * stage;
         st.cslot = (st.rA + 64 * SL_CR) % SL_CR;
