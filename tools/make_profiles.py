@@ -30,7 +30,7 @@ def short(name):
 def level_of(name, dur_ns):
     # both pyramid levels launch k_hs_stream; the full-resolution launches are the long ones
     if "k_hs_stream" in name:
-        return "4096x4096" if dur_ns > 120000 else "2048x2048"
+        return "4096x4096" if dur_ns > 100000 else "2048x2048"
     return ""
 
 

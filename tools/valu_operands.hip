@@ -42,6 +42,30 @@ __global__ void __launch_bounds__(1024) k_rate(float *out, int iters, float sa, 
 #define S(X) asm volatile("v_add_f32_dpp %0, %1, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(X) : "v"(y));
             REP8(S(x0) S(x1) S(x2) S(x3) S(x4) S(x5) S(x6) S(x7))
 #undef S
+        } else if (KIND == 8) { // fmac (32-bit encoding), vector sources
+#define S(X) asm volatile("v_fmac_f32_e32 %0, %1, %2" : "+v"(X) : "v"(y), "v"(z));
+            REP8(S(x0) S(x1) S(x2) S(x3) S(x4) S(x5) S(x6) S(x7))
+#undef S
+        } else if (KIND == 9) { // fmac (32-bit encoding), scalar first source
+#define S(X) asm volatile("v_fmac_f32_e32 %0, %1, %2" : "+v"(X) : "s"(sa), "v"(z));
+            REP8(S(x0) S(x1) S(x2) S(x3) S(x4) S(x5) S(x6) S(x7))
+#undef S
+        } else if (KIND == 10) { // mul (32-bit encoding), scalar first source
+#define S(X) asm volatile("v_mul_f32_e32 %0, %1, %0" : "+v"(X) : "s"(sa));
+            REP8(S(x0) S(x1) S(x2) S(x3) S(x4) S(x5) S(x6) S(x7))
+#undef S
+        } else if (KIND == 11) { // mul with a 32-bit literal (64-bit encoding)
+#define S(X) asm volatile("v_mul_f32_e32 %0, 0x3daaaaab, %0" : "+v"(X));
+            REP8(S(x0) S(x1) S(x2) S(x3) S(x4) S(x5) S(x6) S(x7))
+#undef S
+        } else if (KIND == 12) { // add, 64-bit (VOP3) encoding of the same operation
+#define S(X) asm volatile("v_add_f32_e64 %0, %0, %1" : "+v"(X) : "v"(y));
+            REP8(S(x0) S(x1) S(x2) S(x3) S(x4) S(x5) S(x6) S(x7))
+#undef S
+        } else if (KIND == 13) { // fma with the accumulator as third source (what fmac computes), 64-bit encoding
+#define S(X) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(X) : "v"(y), "v"(z));
+            REP8(S(x0) S(x1) S(x2) S(x3) S(x4) S(x5) S(x6) S(x7))
+#undef S
         } else if (KIND == 7) { // packed fma, 1 vector source pair
 #define S(X) asm volatile("v_pk_fma_f32 %0, %0, %1, 0.5" : "+v"(X) : "s"((double)sa));
             REP8(S(p0) S(p1) S(p2) S(p3) S(p4) S(p5) S(p6) S(p7))
@@ -77,7 +101,13 @@ int main() {
     run<1>("v_fma_f32, 2 vector sources", d, ncu, clk);
     run<2>("v_fma_f32, 3 vector sources", d, ncu, clk);
     run<3>("v_add_f32, 2 vector sources", d, ncu, clk);
+    run<12>("v_add_f32_e64 (64-bit encoding)", d, ncu, clk);
     run<6>("v_add_f32 dpp wave_shr:1", d, ncu, clk);
+    run<8>("v_fmac_f32_e32 v, v, v", d, ncu, clk);
+    run<9>("v_fmac_f32_e32 v, s, v", d, ncu, clk);
+    run<13>("v_fma_f32 v, v, v, acc (64-bit)", d, ncu, clk);
+    run<10>("v_mul_f32_e32 v, s, v", d, ncu, clk);
+    run<11>("v_mul_f32_e32 v, literal, v", d, ncu, clk);
     run<7>("v_pk_fma_f32, 1 vector source", d, ncu, clk);
     run<4>("v_pk_fma_f32, 3 vector sources", d, ncu, clk);
     run<5>("v_pk_add_f32, 2 vector sources", d, ncu, clk);
