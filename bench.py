@@ -26,8 +26,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "opticalflow-ri_amd")]
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak
+HBM_COPY_GBS = 4700.0          # what a device-to-device copy of 4 GiB sustains on the box (read + write; tools/hbm_copy_rate.py)
 HS_BYTES_PER_PX_SWEEP = 28.0   # one Jacobi sweep: read U,V and three coefficient planes + write U,V, float32
-VALU_LANE_OPS_PER_S = 256 * 4 * 16 * 2.4e9      # 256 CUs x 4 SIMDs x 16 lanes per clock x 2.4 GHz, non-packed fp32
+VALU_LANE_OPS_PER_S = 256 * 4 * 16 * 2.4e9      # 256 CUs x 4 SIMDs x one wavefront instruction per 4 cycles (the rate of fused
+                                                # multiply-adds, tools/valu_operands.hip) x 2.4 GHz, one operation per lane
 HS_OPS_PER_PX_SWEEP = 14       # vector operations per pixel and sweep of the fast kernels (ofri_hs_math.h)
 
 
@@ -183,12 +185,17 @@ def roofline_block(recs, H, W, steps, ms_per_step):
     traffic = _committed("pmc_traffic.json").get(key)              # HBM bytes per launch from the committed PMC passes
     sq = _committed("pmc_sq.json").get(key)                         # issue fractions from the committed SQ pass
     useful = HS_OPS_PER_PX_SWEEP * H * W * spl / VALU_LANE_OPS_PER_S * 1e3          # ms of vector issue the sweeps need
+    hbm_meas = (traffic / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None
+    # A blocked launch is bound by what the measurements show: memory once its counted traffic moves at the rate a plain
+    # copy sustains (a launch of a third of the sweeps then takes the same time), vector issue below that.
+    mem_bound = hbm_meas is not None and hbm_meas * HBM_PEAK_GBS >= 0.85 * HBM_COPY_GBS
     block = {
-        "bound": "valu-issue" if blocked else "hbm",
+        "bound": ("hbm" if mem_bound else "valu-issue") if blocked else "hbm",
         "kernel": key, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
         "traffic": traffic, "launch_ms": launch_ms, "launches_timed": launches, "sweeps_per_launch": spl,
         "algorithmic_bytes_per_launch": alg_launch,
-        "hbm_frac_measured": (traffic / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+        "hbm_frac_measured": hbm_meas,
+        "hbm_frac_of_copy_rate": (hbm_meas * HBM_PEAK_GBS / HBM_COPY_GBS) if hbm_meas is not None else None,
         # the same launch against the per-sweep byte model (what separate sweeps would have to move): above the HBM
         # peak by construction when sweeps are blocked on chip; not a roofline fraction
         "effective_per_sweep_GBs": HS_BYTES_PER_PX_SWEEP * H * W * spl / (launch_ms * 1e-3) / 1e9,
