@@ -222,6 +222,32 @@ def test_hs_accumulating_step_equals_step_plus_add(ctx, shape, nit, zero):
     np.testing.assert_array_equal(Ua.numpy(), want[0]); np.testing.assert_array_equal(Va.numpy(), want[1])
 
 
+@pytest.mark.parametrize("shape,nit,zero", [((700, 1000), 24, True), ((1030, 2052), 28, False), ((300, 520), 12, False)])
+def test_hs_accumulating_store_in_wide_strips(ctx, shape, nit, zero):
+    """The accumulating store of the pipeline's 256-column strips (the launch shape of 4096 x 4096 fields, forced here on
+    smaller ones, ragged against the strips and chunks): the bits of one sweep per launch followed by the float32 addition."""
+    from HornSchunck import HSOpticalFlowAlgoAdapter, hs_device
+    from piv_synth import synth_piv
+    a, b = synth_piv(shape[0], shape[1], seed=4)
+    rng = np.random.default_rng(nit + shape[0])
+    acc = [rng.standard_normal(shape).astype(np.float32) for _ in range(2)]
+    start = [None, None] if zero else [ctx.upload(rng.standard_normal(shape).astype(np.float32) * 0.1) for _ in range(2)]
+    fa, fb = ctx.upload(a.astype(np.float32)), ctx.upload(b.astype(np.float32))
+    ctx.set_hs_fuse(1)
+    try:
+        Un, Vn, _ = hs_device(fa, fb, 21.0, nit, start[0], start[1], want_error=False)
+    finally:
+        ctx.set_hs_fuse(0)
+    want = (acc[0] + Un.numpy(), acc[1] + Vn.numpy())
+    Ua, Va = ctx.upload(acc[0]), ctx.upload(acc[1])
+    ctx.set_hs_fuse(32)
+    try:
+        HSOpticalFlowAlgoAdapter([21.0], nit).accumulate_device(fa, fb, start[0], start[1], Ua, Va)
+    finally:
+        ctx.set_hs_fuse(0)
+    np.testing.assert_array_equal(Ua.numpy(), want[0]); np.testing.assert_array_equal(Va.numpy(), want[1])
+
+
 @pytest.mark.parametrize("shape,ksize,warp,nit", [((2048, 2048), 3, True, 28), ((2048, 2048), 3, False, 28), ((2050, 2052), 5, True, 16),
                                                    ((2049, 2052), 7, True, 28), ((2049, 2052), 7, False, 24), ((96, 128), 3, True, 20),
                                                    ((2048, 2048), 9, True, 28)])
