@@ -284,6 +284,9 @@ def emit(result, real_stdout):
 
 def main():
     args = parse()
+    if os.environ.get("OFRI_BENCH_WATCHDOG"):       # seconds after which every thread's stack is dumped and the run ends
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["OFRI_BENCH_WATCHDOG"]), exit=True)
     # Everything but the result line goes to standard error: libraries print banners to file descriptor 1 (RCCL its
     # version block when the first communicator is made), and the contract is one JSON line on standard output.
     real_stdout = os.dup(1)

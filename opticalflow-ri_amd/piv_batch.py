@@ -219,25 +219,32 @@ def run_batch(n_pairs, pair_fn, flow_fn, ctx=None, group=None, dst=0, chunk=8, g
     state = {"send": None, "result": None, "local": None, "shape": None, "comm": None}
     pending = []            # gathers in flight, oldest first: (work handle, send buffer index)
 
+    # A gloo group exchanges host tensors: fields computed on the GPU are then downloaded into host send buffers (gloo's own
+    # staging of GPU tensors hung in its second gather when two ranks shared a GPU).  RCCL takes the GPU tensors as they are.
+    host_exchange = on_gpu and do_gather and job.dist.get_backend(group) == "gloo"
+
     def setup(hw):
         """Buffers, once the field shape is known (every pair of a batch has the same shape)."""
-        job.device = torch.device("cuda", ctx.device) if on_gpu else torch.device("cpu")
+        job.device = torch.device("cuda", ctx.device) if (on_gpu and not host_exchange) else torch.device("cpu")
         H, W = int(hw[0]), int(hw[1])
         state["shape"] = (H, W)
         if do_gather:
             state["send"] = [torch.empty((chunk, 2, H, W), dtype=torch.float32, device=job.device) for _ in range(2)]
             if job.rank == dst:     # rank r's chunk c lands in result[r, c*chunk:(c+1)*chunk]: a contiguous view each
                 state["result"] = torch.empty((job.world, n_chunks * chunk, 2, H, W), dtype=torch.float32, device=job.device)
-            if on_gpu:
+            if on_gpu and not host_exchange:
                 state["comm"] = torch.cuda.Stream(device=job.device)
         else:
             state["local"] = torch.empty((n_local, 2, H, W), dtype=torch.float32, device=job.device)
 
     def store(dst_t, U, V, lctx):
         """Copy one flow field into dst_t (2, H, W) in the order of the lane's stream."""
-        if on_gpu and isinstance(U, _ofri.DeviceArray):
+        if on_gpu and isinstance(U, _ofri.DeviceArray) and dst_t.is_cuda:
             _ofri.check(lib.ofri_copy(lctx.handle, dst_t[0].data_ptr(), U.ptr, U.nbytes))
             _ofri.check(lib.ofri_copy(lctx.handle, dst_t[1].data_ptr(), V.ptr, V.nbytes))
+        elif isinstance(U, _ofri.DeviceArray):                   # host exchange: download (waits for the lane's stream)
+            dst_t[0].copy_(torch.from_numpy(U.numpy()))
+            dst_t[1].copy_(torch.from_numpy(V.numpy()))
         else:
             dst_t[0].copy_(torch.from_numpy(np.ascontiguousarray(U, dtype=np.float32)))
             dst_t[1].copy_(torch.from_numpy(np.ascontiguousarray(V, dtype=np.float32)))
@@ -262,9 +269,10 @@ def run_batch(n_pairs, pair_fn, flow_fn, ctx=None, group=None, dst=0, chunk=8, g
         while len(pending) >= 2:
             w = pending.pop(0)
             w.wait()                                             # orders the current stream (lane 0) after the gather
-            for st in lane_streams[1:]:                          # and every other lane's
-                with torch.cuda.stream(st):
-                    w.wait()
+            if state["comm"] is not None:
+                for st in lane_streams[1:]:                      # and every other lane's
+                    with torch.cuda.stream(st):
+                        w.wait()
 
     if shape is not None:
         setup(shape)
