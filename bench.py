@@ -3,7 +3,10 @@
 
 One step = one frame pair through the whole hot path with the reference's example parameters
 (Gaussian pre-filter Fs 3.4, 2 pyramid levels, alphas [21, 45], 100 Jacobi sweeps per level), inputs
-already resident in HBM as float32.  N GPUs = N ranks, each with its own pairs (weak scaling): the pairs are
+already resident in HBM as float32.  The pair's launches are captured once into a HIP graph (piv_plan.FlowPlan, the
+library's path for streams of equally sized pairs) and a step replays it; the Horn-Schunck sweep launches are timed
+sections of that graph (event nodes), so the roofline block is measured inside the timed steps.  ``--direct`` launches
+kernel by kernel through the driver instead.  N GPUs = N ranks, each with its own pairs (weak scaling): the pairs are
 independent, so the timed path has no exchange between ranks (barrier before and after, time = the slowest rank's);
 ``--gather`` adds the asynchronous gather of every pair's flow field to rank 0 over RCCL, overlapped with the next pair.
 
@@ -54,7 +57,9 @@ def parse():
     ap.add_argument("--force-dist", action="store_true", help="take the multi-rank code path (process group, gather stream, "
                     "barriers) even with one rank: rehearsal of the N > 1 path on a one-GPU box")
     ap.add_argument("--with-transfer", action="store_true", help="also report the rate including H2D/D2H copies")
-    ap.add_argument("--graph", action="store_true", help="replay the pair's launches from a captured HIP graph (piv_plan.FlowPlan)")
+    ap.add_argument("--graph", action="store_true", help="(default) replay the pair's launches from a captured HIP graph (piv_plan.FlowPlan)")
+    ap.add_argument("--direct", action="store_true", help="launch kernel by kernel through the driver instead of replaying the captured "
+                    "graph (the gaps between a pair's 24 launches then cost about 5 %% at 4096 x 4096)")
     ap.add_argument("--in-flight", type=int, default=0, help="with --graph: pairs per step, each on its own context/stream (default 1); "
                     "with --batch: pairs in flight per GPU (default 3) "
                     "(small frames do not fill the GPU one pair at a time)")
@@ -64,6 +69,7 @@ def parse():
     ap.add_argument("--distinct", type=int, default=4, help="with --batch: distinct synthetic pairs generated per rank (cycled; "
                     "rendering one 2048x2048 pair takes 0.5 s of host time)")
     a = ap.parse_args()
+    a.graph = not a.direct
     if a.size is None:
         a.size = 2048 if a.batch else 4096
     return a
@@ -371,9 +377,19 @@ def main():
         opt_args = {"FILTER_OPT": 0.48, "optionalOFlowAlgoAdapter": LiuShenOpticalFlowAlgoAdapter(5)}
     plan = None
     extra = []                      # further (context, plan) pairs when several frame pairs are in flight
-    if args.graph:
+    graph_note = None
+    if args.graph and multi:
+        # ranks under torch.distributed keep the kernel-by-kernel path: torch's wheel brings its own HIP runtime, which
+        # refused the event nodes of a timed capture when tried
+        graph_note = "kernel by kernel: timed graph capture is used on one rank only"
+    elif args.graph:
         from piv_plan import FlowPlan
-        plan = FlowPlan((H, W), 3.4, lambda: HSOpticalFlowAlgoAdapter([21, 45], args.niter), pyramidalLevels=2, ctx=ctx, **opt_args)
+        # the sweep launches are timed sections of the graph: every replay times them (event nodes on the context's stream)
+        try:
+            plan = FlowPlan((H, W), 3.4, lambda: HSOpticalFlowAlgoAdapter([21, 45], args.niter), pyramidalLevels=2, ctx=ctx, timed=True, **opt_args)
+        except _ofri.OfriError as e:
+            plan, graph_note = None, "kernel by kernel: timed graph capture failed (%s)" % (str(e)[:120],)
+    if plan is not None:
         plan.load(im0, im1)
         for k in range(1, max(1, args.in_flight)):
             c = _ofri.Context(dev)
@@ -426,14 +442,18 @@ def main():
     for i in range(args.warmup):
         step(i)
     fence()
-    ctx.prof_enable(True)
+    if plan is None:
+        ctx.prof_enable(True)
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
     fence()
     dt = time.perf_counter() - t0
-    recs = ctx.prof_records()
-    ctx.prof_enable(False)
+    if plan is None:
+        recs, rec_steps = ctx.prof_records(), args.steps
+        ctx.prof_enable(False)
+    else:
+        recs, rec_steps = plan.prof_records(), 1            # the graph's sections as its last replay timed them
 
     if multi:
         from piv_batch import max_over_ranks
@@ -443,7 +463,9 @@ def main():
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = world * pairs_per_step * H * W * args.steps / dt / 1e6
-        roof = roofline_block(recs, H, W, args.steps, ms_per_step) if not args.graph else None
+        roof = roofline_block(recs, H, W, rec_steps, ms_per_step)
+        if roof is not None and plan is not None:
+            roof["timed_in"] = "the last of the %d replays of the captured graph" % args.steps
         if roof is not None and world == 1 and args.fuse == 0:
             roof["one_sweep_kernel"] = one_sweep_roofline(ctx, H, W)
         result = {
@@ -453,11 +475,11 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "HS Fs3.4, 2-level pyramid, %dx%d synthetic Poiseuille pair, alphas [21,45], "
                                    "%d sweeps/level%s" % (H, W, args.niter, " + Liu-Shen h=5 Fs_opt 0.48 on every level" if args.liushen else ""),
-                       "pairs_per_step_per_gpu": pairs_per_step, "flow_gather": gather_note, "captured_graph": bool(args.graph),
+                       "pairs_per_step_per_gpu": pairs_per_step, "flow_gather": gather_note, "captured_graph": plan is not None, "launch_mode_note": graph_note,
                        "hs_sweeps_per_launch": roof["sweeps_per_launch"] if roof else None},
             "roofline": roof,
         }
-    if rank == 0 and world == 1 and not args.graph and not args.no_in_flight:
+    if rank == 0 and world == 1 and pairs_per_step == 1 and not args.no_in_flight:
         # throughput figure beside the headline: three pairs in flight, each replayed from its own captured graph on its
         # own stream (one pair's launches leave gaps and tails that another pair's fill); not `value`, which stays one
         # pair per step with the roofline measured inside it
@@ -476,12 +498,26 @@ def main():
             for c, _ in lanes:
                 c.sync()
         rounds(2)
-        # one pair at a time from its captured graph: the headline's work without the gaps between its 24 launches
-        t = time.perf_counter()
-        rounds(args.steps, lanes[:1])
-        dt1 = time.perf_counter() - t
-        result["one_pair_captured_graph"] = {"value": H * W * args.steps / dt1 / 1e6, "unit": "Mpix/s",
-                                             "ms_per_pair": dt1 / args.steps * 1e3}
+        if plan is None:
+            # one pair at a time from its captured graph: the headline's work without the gaps between its 24 launches
+            t = time.perf_counter()
+            rounds(args.steps, lanes[:1])
+            dt1 = time.perf_counter() - t
+            result["one_pair_captured_graph"] = {"value": H * W * args.steps / dt1 / 1e6, "unit": "Mpix/s",
+                                                 "ms_per_pair": dt1 / args.steps * 1e3}
+        else:
+            # the same pair launched kernel by kernel through the driver (what a caller without a plan gets)
+            def direct(n):
+                for _ in range(n):
+                    pyramidal_flow_device(im0, im1, 3.4, HSOpticalFlowAlgoAdapter([21, 45], args.niter), 2, 1,
+                                          opt_args.get("FILTER_OPT"), opt_args.get("optionalOFlowAlgoAdapter"))
+                ctx.sync()
+            direct(2)
+            t = time.perf_counter()
+            direct(args.steps)
+            dtd = time.perf_counter() - t
+            result["kernel_by_kernel"] = {"value": H * W * args.steps / dtd / 1e6, "unit": "Mpix/s",
+                                          "ms_per_pair": dtd / args.steps * 1e3}
         t = time.perf_counter()
         rounds(args.steps)
         dt3 = time.perf_counter() - t
@@ -497,6 +533,8 @@ def main():
             a_d, b_d = ctx.upload(f0, np.uint8), ctx.upload(f1, np.uint8)
             _ofri.check(lib.ofri_u8_to_f32(ctx.handle, a_d.ptr, im0.ptr, H * W))
             _ofri.check(lib.ofri_u8_to_f32(ctx.handle, b_d.ptr, im1.ptr, H * W))
+            if plan is not None:
+                plan.load(im0, im1)
             Ua, Va = step(i)
             Ua.numpy(); Va.numpy()
         result["with_transfer_mpix_s"] = H * W * 3 / (time.perf_counter() - t) / 1e6

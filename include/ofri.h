@@ -90,6 +90,11 @@ int ofri_graph_begin(ofri_ctx *ctx);
 int ofri_graph_end(ofri_ctx *ctx, ofri_graph **graph);
 int ofri_graph_launch(ofri_ctx *ctx, ofri_graph *graph);
 int ofri_graph_destroy(ofri_graph *graph);       /* before ofri_ctx_destroy */
+/* A capture that runs with ofri_prof_enable(ctx, 1) records the timed sections (the Horn-Schunck sweep launches, see
+ * ofri_prof_read) into the graph as event nodes: every replay times them again.  ofri_graph_prof_read waits for the
+ * section's end in the graph's last replay and returns what ofri_prof_read returns.  No reference counterpart. */
+int ofri_graph_prof_count(ofri_graph *graph, int *count);
+int ofri_graph_prof_read(ofri_graph *graph, int idx, float *ms, int *launches, int *sweeps, int *rows, int *cols);
 
 /* HIP events on the context's stream, for timing kernels from a host language */
 int ofri_event_create(ofri_ctx *ctx, ofri_event **ev);

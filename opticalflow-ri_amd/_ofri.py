@@ -49,6 +49,8 @@ _PROTOS = {
     "ofri_graph_end": ([_vp, C.POINTER(_vp)], _i),
     "ofri_graph_launch": ([_vp, _vp], _i),
     "ofri_graph_destroy": ([_vp], _i),
+    "ofri_graph_prof_count": ([_vp, C.POINTER(_i)], _i),
+    "ofri_graph_prof_read": ([_vp, _i, C.POINTER(_f), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)], _i),
     "ofri_event_create": ([_vp, C.POINTER(_vp)], _i),
     "ofri_event_record": ([_vp, _vp], _i),
     "ofri_event_elapsed_ms": ([_vp, _vp, C.POINTER(_f)], _i),
@@ -338,6 +340,18 @@ class Graph(object):
 
     def launch(self):
         check(lib().ofri_graph_launch(self.ctx.handle, self._g))
+
+    def prof_records(self):
+        """[(ms, launches, sweeps, rows, cols)] of the timed sections captured into the graph (the capture ran with
+        Context.prof_enable on), as timed by the graph's last replay."""
+        n = _i(0)
+        check(lib().ofri_graph_prof_count(self._g, C.byref(n)))
+        out = []
+        for k in range(n.value):
+            ms, la, sw, r, c = _f(0), _i(0), _i(0), _i(0), _i(0)
+            check(lib().ofri_graph_prof_read(self._g, k, C.byref(ms), C.byref(la), C.byref(sw), C.byref(r), C.byref(c)))
+            out.append((ms.value, la.value, sw.value, r.value, c.value))
+        return out
 
     def close(self):
         if self._g and self.ctx._h:

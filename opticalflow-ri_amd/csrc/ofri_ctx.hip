@@ -158,9 +158,9 @@ extern "C" int ofri_free(ofri_ctx *ctx, void *dptr) {
 extern "C" int ofri_graph_begin(ofri_ctx *ctx) {
     OFRI_TRY(ofri_check_ctx(ctx));
     OFRI_REQUIRE(!ctx->capturing, "a capture is already running on this context");
-    OFRI_REQUIRE(!ctx->prof, "switch the sweep timing off before capturing (ofri_prof_enable(ctx, 0))");
     OFRI_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed));
     ctx->capturing = true;
+    ctx->cap_prof_recs.clear();
     ctx->cap_pool.clear();
     ctx->cap_blocks.clear();
     return OFRI_OK;
@@ -186,15 +186,18 @@ extern "C" int ofri_graph_end(ofri_ctx *ctx, ofri_graph **out) {
     hipGraphExec_t exec = nullptr;
     hipError_t e2 = hipSuccess;
     if (e == hipSuccess && g) e2 = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
+    std::vector<ofri_ctx::ProfRec> timed = std::move(ctx->cap_prof_recs);
+    ctx->cap_prof_recs.clear();
     if (e != hipSuccess || !g || e2 != hipSuccess) {
         if (g) (void)hipGraphDestroy(g);
+        for (auto &r : timed) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
         for (auto &b : owned) ctx->pool[b.second].push_back(b.first);
         (void)hipGetLastError();
         return ofri_set_error(OFRI_EHIP, "stream capture failed: %s (a call that waits for the GPU or copies to pageable "
                               "host memory cannot be captured)", hipGetErrorString(e != hipSuccess ? e : e2));
     }
     ofri_graph *gr = new ofri_graph();
-    gr->ctx = ctx; gr->graph = g; gr->exec = exec; gr->blocks = std::move(owned);
+    gr->ctx = ctx; gr->graph = g; gr->exec = exec; gr->blocks = std::move(owned); gr->prof_recs = std::move(timed);
     for (void *p : held) ctx->graph_held[p] = gr;
     *out = gr;
     return OFRI_OK;
@@ -208,11 +211,29 @@ extern "C" int ofri_graph_launch(ofri_ctx *ctx, ofri_graph *graph) {
     return OFRI_OK;
 }
 
+// Timed sections captured into the graph (the capture ran with ofri_prof_enable on): their count, and one section's
+// duration in the graph's last replay (waits for that replay's end of the section).
+extern "C" int ofri_graph_prof_count(ofri_graph *graph, int *count) {
+    OFRI_REQUIRE(graph && count, "null argument");
+    *count = (int)graph->prof_recs.size();
+    return OFRI_OK;
+}
+extern "C" int ofri_graph_prof_read(ofri_graph *graph, int idx, float *ms, int *launches, int *sweeps, int *rows, int *cols) {
+    OFRI_REQUIRE(graph && ms && launches && sweeps && rows && cols, "null argument");
+    OFRI_REQUIRE(idx >= 0 && idx < (int)graph->prof_recs.size(), "record index out of range");
+    auto &r = graph->prof_recs[idx];
+    OFRI_HIP(hipEventSynchronize(r.b));
+    OFRI_HIP(hipEventElapsedTime(ms, r.a, r.b));
+    *launches = r.launches; *sweeps = r.sweeps; *rows = r.rows; *cols = r.cols;
+    return OFRI_OK;
+}
+
 // the context must still exist; the graph's scratch memory goes back to its pool
 extern "C" int ofri_graph_destroy(ofri_graph *graph) {
     if (!graph) return OFRI_OK;
     (void)hipGraphExecDestroy(graph->exec);
     (void)hipGraphDestroy(graph->graph);
+    for (auto &r : graph->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto &b : graph->blocks) graph->ctx->pool[b.second].push_back(b.first);
     for (auto it = graph->ctx->graph_held.begin(); it != graph->ctx->graph_held.end();)      // what the caller still holds is plain memory again
         it = it->second == graph ? graph->ctx->graph_held.erase(it) : std::next(it);

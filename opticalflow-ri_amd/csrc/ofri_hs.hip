@@ -176,17 +176,21 @@ extern "C" int ofri_hs_set_fuse(ofri_ctx *ctx, int sweeps_per_launch) {
     return OFRI_OK;
 }
 
+// Timed sections.  While the context captures a graph the events become event-record nodes of the graph (recorded again
+// at every replay) and the section belongs to the graph (ofri_graph_prof_read).
 static int prof_begin(ofri_ctx *ctx, ofri_ctx::ProfRec &rec) {
     if (!ctx->prof) return OFRI_OK;
     OFRI_HIP(hipEventCreate(&rec.a)); OFRI_HIP(hipEventCreate(&rec.b));
-    OFRI_HIP(hipEventRecord(rec.a, ctx->stream));
+    if (ctx->capturing) OFRI_HIP(hipEventRecordWithFlags(rec.a, ctx->stream, hipEventRecordExternal));
+    else OFRI_HIP(hipEventRecord(rec.a, ctx->stream));
     return OFRI_OK;
 }
 static int prof_end(ofri_ctx *ctx, ofri_ctx::ProfRec &rec, int rows, int cols, int launches, int sweeps) {
     if (!ctx->prof) return OFRI_OK;
-    OFRI_HIP(hipEventRecord(rec.b, ctx->stream));
+    if (ctx->capturing) OFRI_HIP(hipEventRecordWithFlags(rec.b, ctx->stream, hipEventRecordExternal));
+    else OFRI_HIP(hipEventRecord(rec.b, ctx->stream));
     rec.rows = rows; rec.cols = cols; rec.launches = launches; rec.sweeps = sweeps;
-    ctx->prof_recs.push_back(rec);
+    (ctx->capturing ? ctx->cap_prof_recs : ctx->prof_recs).push_back(rec);
     return OFRI_OK;
 }
 

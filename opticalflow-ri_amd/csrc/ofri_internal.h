@@ -29,6 +29,7 @@ struct ofri_ctx {
     bool prof = false;
     struct ProfRec { hipEvent_t a, b; int rows, cols, launches, sweeps; };
     std::vector<ProfRec> prof_recs;
+    std::vector<ProfRec> cap_prof_recs;                // timed sections recorded into the capture under way (they go to its graph)
     // stream capture (ofri_graph_begin .. ofri_graph_end): blocks handed out while capturing are recycled among
     // the captured work only and end up owned by the graph, so nothing else is ever given memory the graph writes
     bool capturing = false;
@@ -44,6 +45,7 @@ struct ofri_graph {
     hipGraph_t graph;
     hipGraphExec_t exec;
     std::vector<std::pair<void *, size_t>> blocks;     // scratch memory of the captured work
+    std::vector<ofri_ctx::ProfRec> prof_recs;          // timed sections inside the graph: their events are recorded at every replay
 };
 
 struct ofri_event {

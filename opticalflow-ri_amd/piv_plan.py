@@ -23,7 +23,9 @@ class FlowPlan(object):
     bilinear warp or none.  Sequences that read something back (the biLinear=False warp's range check) raise
     OfriError at construction."""
 
-    def __init__(self, shape, FILTER, make_adapter, pyramidalLevels=1, kLevels=1, FILTER_OPT=None, ctx=None, **driver_args):
+    def __init__(self, shape, FILTER, make_adapter, pyramidalLevels=1, kLevels=1, FILTER_OPT=None, ctx=None, timed=False,
+                 **driver_args):
+        """``timed``: capture the Horn-Schunck sweep launches as timed sections (prof_records() after a run)."""
         self.ctx = ctx if ctx is not None else _ofri.context()
         self.shape = (int(shape[0]), int(shape[1]))
         self.im1, self.im2 = self.ctx.zeros(self.shape), self.ctx.zeros(self.shape)
@@ -33,16 +35,26 @@ class FlowPlan(object):
                                          FILTER_OPT, **driver_args)
 
         run()                               # builds the cached tables and fills the pool: the capture allocates nothing new
-        self.ctx.graph_begin()
+        if timed:
+            self.ctx.prof_enable(True)
         try:
-            self.U, self.V = run()
-        except Exception:
+            self.ctx.graph_begin()
             try:
-                self.ctx.graph_end().close()
-            except _ofri.OfriError:
-                pass
-            raise
-        self.graph = self.ctx.graph_end()
+                self.U, self.V = run()
+            except Exception:
+                try:
+                    self.ctx.graph_end().close()
+                except _ofri.OfriError:
+                    pass
+                raise
+            self.graph = self.ctx.graph_end()
+        finally:
+            if timed:
+                self.ctx.prof_enable(False)
+
+    def prof_records(self):
+        """Timed sections of the last run (a plan made with timed=True): [(ms, launches, sweeps, rows, cols)]."""
+        return self.graph.prof_records()
 
     def load(self, frame1, frame2):
         """Put a pair into the plan's input arrays: NumPy arrays (uint8, uint16 or anything float32 holds) or

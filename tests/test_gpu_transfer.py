@@ -91,6 +91,41 @@ def test_driver_accepts_uint8_frames_like_float32_frames(pair):
 
 
 # ------------------------------------------------------------------------------ captured pipelines
+
+def test_flow_plan_times_its_sweep_launches_at_every_replay():
+    """A plan captured with timed=True holds the Horn-Schunck sweep launches as timed sections of its graph: every
+    replay times them again (event nodes), the results stay the driver's bits, and the sections add up to less than
+    the replay itself."""
+    import _ofri
+    from GenericPyramidalOpticalFlow import genericPyramidalOpticalFlow
+    from HornSchunck import HSOpticalFlowAlgoAdapter
+    from piv_plan import FlowPlan
+    from piv_synth import synth_piv
+    ctx = _ofri.context(0)
+    shape = (2048, 2048)
+    plan = FlowPlan(shape, 3.4, lambda: HSOpticalFlowAlgoAdapter([21, 45], 40), pyramidalLevels=2, timed=True)
+    seen = []
+    for seed in (1, 2):
+        a, b = synth_piv(shape[0], shape[1], seed=seed)
+        plan.load(a, b)
+        e0, e1 = ctx.event(), ctx.event()
+        ctx.record(e0)
+        U, V = plan.run()
+        ctx.record(e1)
+        whole = ctx.elapsed_ms(e0, e1)
+        recs = plan.prof_records()
+        # two levels; the full-resolution one goes through the pipeline (launches of 12 sweeps and a deeper one),
+        # the half-resolution one through the tile kernel
+        assert sorted(set((r[3], r[4]) for r in recs)) == [(1024, 1024), (2048, 2048)]
+        assert sum(r[2] for r in recs) == 80 and all(r[0] > 0 for r in recs)
+        assert sum(r[0] for r in recs) < whole
+        seen.append([r[0] for r in recs])
+        Ur, Vr = genericPyramidalOpticalFlow(a.astype(np.float32), b.astype(np.float32), 3.4,
+                                             HSOpticalFlowAlgoAdapter([21, 45], 40), 2, 1, None)
+        assert U.numpy().tobytes() == Ur.tobytes() and V.numpy().tobytes() == Vr.tobytes()
+    assert ctx.prof_records() == []                     # the sections belong to the graph, not to the context
+    plan.close()
+
 @pytest.mark.parametrize("shape,levels", [((256, 256), 2), ((200, 312), 1), ((2048, 2048), 2)])
 def test_flow_plan_replays_the_driver_bit_for_bit(shape, levels):
     """FlowPlan (the driver's launches captured into a HIP graph) against genericPyramidalOpticalFlow on several
