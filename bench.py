@@ -378,17 +378,17 @@ def main():
     plan = None
     extra = []                      # further (context, plan) pairs when several frame pairs are in flight
     graph_note = None
-    if args.graph and multi:
-        # ranks under torch.distributed keep the kernel-by-kernel path: torch's wheel brings its own HIP runtime, which
-        # refused the event nodes of a timed capture when tried
-        graph_note = "kernel by kernel: timed graph capture is used on one rank only"
-    elif args.graph:
+    # The sweep launches are timed sections of the graph: every replay times them (event nodes on the context's stream).
+    # Ranks under torch.distributed replay an untimed graph instead and time the sweep launches in two kernel-by-kernel
+    # steps after the timed region: torch's wheel brings its own HIP runtime, which refused the event nodes when tried.
+    timed_graph = args.graph and not multi
+    if args.graph:
         from piv_plan import FlowPlan
-        # the sweep launches are timed sections of the graph: every replay times them (event nodes on the context's stream)
         try:
-            plan = FlowPlan((H, W), 3.4, lambda: HSOpticalFlowAlgoAdapter([21, 45], args.niter), pyramidalLevels=2, ctx=ctx, timed=True, **opt_args)
+            plan = FlowPlan((H, W), 3.4, lambda: HSOpticalFlowAlgoAdapter([21, 45], args.niter), pyramidalLevels=2, ctx=ctx,
+                            timed=timed_graph, **opt_args)
         except _ofri.OfriError as e:
-            plan, graph_note = None, "kernel by kernel: timed graph capture failed (%s)" % (str(e)[:120],)
+            plan, graph_note = None, "kernel by kernel: graph capture failed (%s)" % (str(e)[:120],)
     if plan is not None:
         plan.load(im0, im1)
         for k in range(1, max(1, args.in_flight)):
@@ -452,8 +452,17 @@ def main():
     if plan is None:
         recs, rec_steps = ctx.prof_records(), args.steps
         ctx.prof_enable(False)
-    else:
+    elif timed_graph:
         recs, rec_steps = plan.prof_records(), 1            # the graph's sections as its last replay timed them
+    else:
+        ctx.prof_enable(True)
+        rec_steps = 2
+        for _ in range(rec_steps):
+            pyramidal_flow_device(im0, im1, 3.4, HSOpticalFlowAlgoAdapter([21, 45], args.niter), 2, 1,
+                                  opt_args.get("FILTER_OPT"), opt_args.get("optionalOFlowAlgoAdapter"))
+        ctx.sync()
+        recs = ctx.prof_records()
+        ctx.prof_enable(False)
 
     if multi:
         from piv_batch import max_over_ranks
@@ -465,7 +474,8 @@ def main():
         value = world * pairs_per_step * H * W * args.steps / dt / 1e6
         roof = roofline_block(recs, H, W, rec_steps, ms_per_step)
         if roof is not None and plan is not None:
-            roof["timed_in"] = "the last of the %d replays of the captured graph" % args.steps
+            roof["timed_in"] = ("the last of the %d replays of the captured graph" % args.steps if timed_graph else
+                                "two kernel-by-kernel steps after the timed replays")
         if roof is not None and world == 1 and args.fuse == 0:
             roof["one_sweep_kernel"] = one_sweep_roofline(ctx, H, W)
         result = {
