@@ -335,8 +335,15 @@ k_fb_window(const float *__restrict__ src, float *__restrict__ dst, float *__res
 #ifndef FB_W16_WAVES
 #define FB_W16_WAVES 3
 #endif
-template <int NP, int MODE, bool FLOW, bool UM = false>
-__global__ void __launch_bounds__(256, FB_W16_WAVES)
+// DMA: the source tiles go from memory straight into LDS (16-byte LDS-DMA loads: no staging registers, no LDS store
+// instructions), which brings the kernel under 128 registers, four workgroups per CU; the next plane's tile is fetched
+// while the current plane's horizontal pass runs.  Needs rows of a multiple of 4 pixels on a 16-byte aligned base and a
+// field at least as wide as a tile with its aprons; tiles at the left and right border fetch clamped 16-byte groups and
+// fill in the border columns from the tile's own interior afterwards.
+typedef __attribute__((address_space(3))) void fb_lds_void;
+typedef const __attribute__((address_space(1))) void fb_gbl_void;
+template <int NP, int MODE, bool FLOW, bool UM = false, bool DMA = false>
+__global__ void __launch_bounds__(256, DMA ? 4 : FB_W16_WAVES)
 k_fb_window16(const float *__restrict__ src, float *__restrict__ dst, float *__restrict__ flowx, float *__restrict__ flowy,
               int H, int W, FbTaps taps, int tiles_x, int ntiles, const float *__restrict__ R0 = nullptr,
               const float *__restrict__ R1 = nullptr, float *__restrict__ Mnext = nullptr) {
@@ -354,35 +361,70 @@ k_fb_window16(const float *__restrict__ src, float *__restrict__ dst, float *__r
     const size_t P = (size_t)H * W;
     const int ly = tid >> 4, xg = tid & 15;                                  // horizontal pass: row (and row + 16), group of 4 columns
     float res[NP][NR][4] = {};
-    // this thread's samples of a plane's 64 x 96 source tile: rows (tid>>5) + 8s, columns (tid&31) + 32q.
-    // All loads of a plane are issued together, and the next plane's are issued before the current
+    // Register staging: this thread's samples of a plane's 64 x 96 source tile are rows (tid>>5) + 8s, columns
+    // (tid&31) + 32q; all loads of a plane are issued together, and the next plane's are issued before the current
     // plane is filtered, so their latency hides behind the arithmetic.
-    unsigned roff[TH / 8], coff[3];     // row and column parts of the offsets; the launcher guarantees rows*cols < 2^32
+    // DMA: wavefront w fetches rows 16w .. 16w+15 of the tile as six loads of 16 bytes per lane.
+    constexpr int NOFF = DMA ? 6 : TH / 8 + 3;
+    unsigned off[NOFF];                 // the launcher guarantees rows*cols < 2^32
+    float pre[DMA ? 1 : NLD];
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool xborder = DMA && (bx < KSH || bx + BL_TX + KSH > W);
+    if (DMA) {
 #pragma unroll
-    for (int sidx = 0; sidx < TH / 8; ++sidx) {
-        int y = by + (tid >> 5) + 8 * sidx - KSH;
-        y = MODE == 0 ? fb_idx(y, H - 1) : clampi(y, 0, H - 1);
-        roff[sidx] = (unsigned)y * (unsigned)W;
+        for (int k = 0; k < 6; ++k) {
+            const int e = wv * (16 * TW) + 256 * k + 4 * (tid & 63), r = e / TW, c = e - r * TW;
+            int y = by + r - KSH;
+            y = MODE == 0 ? fb_idx(y, H - 1) : clampi(y, 0, H - 1);
+            off[k] = (unsigned)y * (unsigned)W + (unsigned)clampi(bx + c - KSH, 0, W - 4);
+        }
+    } else {
+#pragma unroll
+        for (int sidx = 0; sidx < TH / 8; ++sidx) {
+            int y = by + (tid >> 5) + 8 * sidx - KSH;
+            y = MODE == 0 ? fb_idx(y, H - 1) : clampi(y, 0, H - 1);
+            off[sidx] = (unsigned)y * (unsigned)W;
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            int x = bx + (tid & 31) + 32 * q - KSH;
+            off[TH / 8 + q] = (unsigned)(MODE == 0 ? fb_idx(x, W - 1) : clampi(x, 0, W - 1));
+        }
     }
+    auto fetch = [&](const float *sp) {
+        if (DMA) {
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        int x = bx + (tid & 31) + 32 * q - KSH;
-        coff[q] = (unsigned)(MODE == 0 ? fb_idx(x, W - 1) : clampi(x, 0, W - 1));
-    }
-    float pre[NLD];
+            for (int k = 0; k < 6; ++k)
+                __builtin_amdgcn_global_load_lds((fb_gbl_void *)(sp + off[k]), (fb_lds_void *)(&tin[0][0] + wv * (16 * TW) + 256 * k), 16, 0, 0);
+        } else {
 #pragma unroll
-    for (int e = 0; e < NLD; ++e) pre[e] = src[roff[e / 3] + coff[e % 3]];
+            for (int e = 0; e < NLD; ++e) pre[e] = sp[off[e / 3] + off[TH / 8 + e % 3]];
+        }
+    };
+    fetch(src);
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
+        if (DMA) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();            // the tile has landed, and every wavefront is past the horizontal pass before
+            if (xborder) {              // columns left of the field and right of it, from their mirror (clamp) columns
+                const int r = tid >> 2;
 #pragma unroll
-        for (int sidx = 0; sidx < TH / 8; ++sidx)
+                for (int j = 0; j < 4; ++j) {
+                    const int jj = 4 * (tid & 3) + j, xl = -1 - jj, xr = W + jj;
+                    const int cl = xl - bx + KSH, cr = xr - bx + KSH;
+                    if (cl >= 0) tin[r][cl] = tin[r][(MODE == 0 ? fb_idx(xl, W - 1) : 0) - bx + KSH];
+                    if (cr < TW) tin[r][cr] = tin[r][(MODE == 0 ? fb_idx(xr, W - 1) : W - 1) - bx + KSH];
+                }
+                __syncthreads();
+            }
+        } else {
 #pragma unroll
-            for (int q = 0; q < 3; ++q) tin[(tid >> 5) + 8 * sidx][(tid & 31) + 32 * q] = pre[sidx * 3 + q];
-        __syncthreads();
-        if (p + 1 < NP) {
-            const float *sp = src + (size_t)(p + 1) * P;
+            for (int sidx = 0; sidx < TH / 8; ++sidx)
 #pragma unroll
-            for (int e = 0; e < NLD; ++e) pre[e] = sp[roff[e / 3] + coff[e % 3]];
+                for (int q = 0; q < 3; ++q) tin[(tid >> 5) + 8 * sidx][(tid & 31) + 32 * q] = pre[sidx * 3 + q];
+            __syncthreads();
+            if (p + 1 < NP) fetch(src + (size_t)(p + 1) * P);
         }
         static_assert((BW_TY / 4) * TW % 256 == 0, "the vertical pass divides evenly over the workgroup");
 #pragma unroll 1
@@ -403,6 +445,7 @@ k_fb_window16(const float *__restrict__ src, float *__restrict__ dst, float *__r
             }
         }
         __syncthreads();
+        if (DMA && p + 1 < NP) fetch(src + (size_t)(p + 1) * P);    // the source tile's space is free now
 #pragma unroll 1
         for (int h = 0; h < NR; ++h) {
             asm volatile("" ::: "memory");      // one row's window at a time in registers
@@ -488,6 +531,9 @@ k_fb_window16(const float *__restrict__ src, float *__restrict__ dst, float *__r
     }
 }
 
+// the LDS-DMA variant's conditions: 16-byte groups of a row stay inside the row and are aligned
+static inline bool fb_window_dma_ok(const float *src, int cols) { return (cols & 3) == 0 && cols >= BL_TX && (((size_t)src) & 15) == 0; }
+
 template <int NP, int MODE, bool FLOW>
 static int fb_window_launch(ofri_ctx *ctx, const float *src, float *dst, float *fx, float *fy, int rows, int cols,
                             const float *taps_host, int ksh) {
@@ -502,7 +548,8 @@ static int fb_window_launch(ofri_ctx *ctx, const float *src, float *dst, float *
     if (MODE == 0) memcpy(t.k, taps_host, (ksh + 1) * sizeof(float));
     if (ksh == 16 && (size_t)rows * cols < 0xffffffffull) {
         const int tx16 = ceil_div(cols, BL_TX), nt16 = tx16 * ceil_div(rows, BW_TY);
-        k_fb_window16<NP, MODE, FLOW><<<nt16, 256, 0, ctx->stream>>>(src, dst, fx, fy, rows, cols, t, tx16, nt16);
+        if (fb_window_dma_ok(src, cols)) k_fb_window16<NP, MODE, FLOW, false, true><<<nt16, 256, 0, ctx->stream>>>(src, dst, fx, fy, rows, cols, t, tx16, nt16);
+        else k_fb_window16<NP, MODE, FLOW><<<nt16, 256, 0, ctx->stream>>>(src, dst, fx, fy, rows, cols, t, tx16, nt16);
         OFRI_LAUNCH_CHECK();
         return OFRI_OK;
     }
@@ -571,7 +618,10 @@ static int fbk_window5_flow_matrices(ofri_ctx *ctx, const float *M5, float *flow
         memset(&t, 0, sizeof(t));
         if (!box) memcpy(t.k, half_taps_host, 17 * sizeof(float));
         const int tx16 = ceil_div(cols, BL_TX), nt16 = tx16 * ceil_div(rows, BW_TY);
-        if (box) k_fb_window16<5, 1, true, true><<<nt16, 256, 0, ctx->stream>>>(M5, nullptr, flowx, flowy, rows, cols, t, tx16, nt16, R0, R1, M5_next);
+        const bool dma = fb_window_dma_ok(M5, cols);
+        if (box && dma) k_fb_window16<5, 1, true, true, true><<<nt16, 256, 0, ctx->stream>>>(M5, nullptr, flowx, flowy, rows, cols, t, tx16, nt16, R0, R1, M5_next);
+        else if (box) k_fb_window16<5, 1, true, true><<<nt16, 256, 0, ctx->stream>>>(M5, nullptr, flowx, flowy, rows, cols, t, tx16, nt16, R0, R1, M5_next);
+        else if (dma) k_fb_window16<5, 0, true, true, true><<<nt16, 256, 0, ctx->stream>>>(M5, nullptr, flowx, flowy, rows, cols, t, tx16, nt16, R0, R1, M5_next);
         else k_fb_window16<5, 0, true, true><<<nt16, 256, 0, ctx->stream>>>(M5, nullptr, flowx, flowy, rows, cols, t, tx16, nt16, R0, R1, M5_next);
         OFRI_LAUNCH_CHECK();
         return OFRI_OK;

@@ -718,7 +718,8 @@ def test_farneback_fused_iteration_equals_its_steps(ctx, shape, ksh, box, fb_mod
     rng = np.random.default_rng(H * 31 + W + ksh)
     M = ctx.upload((rng.standard_normal((5 * H, W)) * 3).astype(np.float32))
     R0 = ctx.upload(rng.standard_normal((5 * H, W)).astype(np.float32)); R1 = ctx.upload(rng.standard_normal((5 * H, W)).astype(np.float32))
-    taps = np.ascontiguousarray(getGaussianKernelBitExact(2 * ksh + 1, 0.3 * ksh)[ksh:], dtype=np.float32)
+    taps = np.ascontiguousarray(getGaussianKernelBitExact(2 * ksh + 1, 0.3 * ksh)[1][ksh:], dtype=np.float32)
+    assert taps.shape == (ksh + 1,)
     fx, fy, Mref = ctx.empty(shape), ctx.empty(shape), ctx.empty((5 * H, W))
     _ofri.check(lib.ofri_fb_window5_update_flow(ctx.handle, M.ptr, fx.ptr, fy.ptr, H, W, taps.ctypes.data, ksh, box))
     _ofri.check(lib.ofri_fb_update_matrices(ctx.handle, fx.ptr, fy.ptr, R0.ptr, R1.ptr, Mref.ptr, H, W))
@@ -730,6 +731,41 @@ def test_farneback_fused_iteration_equals_its_steps(ctx, shape, ksh, box, fb_mod
     _ofri.check(lib.ofri_fb_window5_flow_matrices(ctx.handle, M.ptr, None, None, R0.ptr, R1.ptr, Mn2.ptr, H, W, taps.ctypes.data, ksh, box))
     assert Mn2.numpy().tobytes() == Mref.numpy().tobytes()
     assert lib.ofri_fb_window5_flow_matrices(ctx.handle, M.ptr, None, None, R0.ptr, R1.ptr, M.ptr, H, W, taps.ctypes.data, ksh, box) != 0
+
+@pytest.mark.parametrize("shape", [(33, 64), (70, 68), (31, 132), (64, 200), (100, 256), (40, 1028)])
+@pytest.mark.parametrize("box", [0, 1])
+def test_farneback_window_tiles_fetched_by_dma_or_through_registers(ctx, shape, box, fb_mode):
+    """The 33 x 33 window fetches its source tiles straight into LDS when rows are 16-byte groups on an aligned base
+    and through registers otherwise: the same planes at an address 4 bytes further take the second way, same bits
+    (plain filter, filter + solve, and the fused iteration)."""
+    import _ofri
+    from GaussianKernelBitExact import getGaussianKernelBitExact
+    lib = _ofri.lib()
+    H, W = shape
+    n = 5 * H * W
+    rng = np.random.default_rng(H + 7 * W + box)
+    host = (rng.standard_normal(n) * 3).astype(np.float32)
+    M = ctx.upload(host)
+    big = ctx.upload(np.concatenate([np.zeros(1, np.float32), host]))
+    assert M.ptr % 16 == 0 and big.ptr % 16 == 0
+    off = big.ptr + 4
+    R0 = ctx.upload(rng.standard_normal((5 * H, W)).astype(np.float32)); R1 = ctx.upload(rng.standard_normal((5 * H, W)).astype(np.float32))
+    taps = np.ascontiguousarray(getGaussianKernelBitExact(33, 4.95)[1][16:], dtype=np.float32)
+    assert taps.shape == (17,)
+    out = []
+    for src in (M.ptr, off):
+        d5, fx, fy, Mn = ctx.zeros((5 * H, W)), ctx.zeros(shape), ctx.zeros(shape), ctx.zeros((5 * H, W))
+        if box:
+            _ofri.check(lib.ofri_fb_box5(ctx.handle, src, d5.ptr, H, W, 16))
+        else:
+            _ofri.check(lib.ofri_fb_blur5(ctx.handle, src, d5.ptr, H, W, taps.ctypes.data, 16))
+        _ofri.check(lib.ofri_fb_window5_update_flow(ctx.handle, src, fx.ptr, fy.ptr, H, W, taps.ctypes.data, 16, box))
+        _ofri.check(lib.ofri_fb_window5_flow_matrices(ctx.handle, src, None, None, R0.ptr, R1.ptr, Mn.ptr, H, W, taps.ctypes.data, 16, box))
+        out.append([a.numpy() for a in (d5, fx, fy, Mn)])
+    for a, b, what in zip(out[0], out[1], ("planes", "flow x", "flow y", "next matrices")):
+        assert a.tobytes() == b.tobytes(), what
+    assert np.isfinite(out[0][0]).all()
+
 
 @pytest.mark.parametrize("kw", [dict(), dict(useGaussian=False, windowSize=15, Niters=3, polyN=5, polySigma=1.1),
                                 dict(pyramidalLevels=3)])
