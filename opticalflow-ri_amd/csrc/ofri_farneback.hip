@@ -22,13 +22,20 @@ __device__ __forceinline__ int fb_idx(int t, int last) { return (unsigned)t <= (
 // ---- updateMatrices border attenuation (.cl:254) ------------------------------------------------------
 __constant__ float c_fb_border[6] = {0.14f, 0.14f, 0.4472f, 0.4472f, 0.4472f, 1.f};
 
+// FB_PIXEL_CONTRACT: the contraction rule inside the per-pixel matrices step, which is instantiated for one pixel and
+// for several in flight and must give the same bits in both: multiply-adds are fused only inside one expression there
+// (the compiler's choice across statements depends on the surrounding code).
 namespace fb_exact {
 #pragma clang fp contract(off)
+#define FB_PIXEL_CONTRACT _Pragma("clang fp contract(off)")
 #include "ofri_farneback_kernels.h"
+#undef FB_PIXEL_CONTRACT
 }  // namespace fb_exact
 namespace fb_fast {
 #pragma clang fp contract(fast)
+#define FB_PIXEL_CONTRACT _Pragma("clang fp contract(on)")
 #include "ofri_farneback_kernels.h"
+#undef FB_PIXEL_CONTRACT
 }  // namespace fb_fast
 #pragma clang fp contract(off)
 

@@ -70,6 +70,10 @@ static int fbk_polyexp(ofri_ctx *ctx, const float *src, float *dst5, int rows, i
     return OFRI_OK;
 }
 
+// address spaces of the LDS-DMA loads (__builtin_amdgcn_global_load_lds)
+typedef __attribute__((address_space(3))) void fb_lds_void;
+typedef const __attribute__((address_space(1))) void fb_gbl_void;
+
 // ---- pre-blur + polynomial expansion in one launch --------------------------------------------------
 // The reference blurs every frame with a 3-tap kernel before expanding it (Farneback_PyCL.py:563-585; with the
 // default single internal level the resize between the two is an identity).  Here a workgroup stages the source
@@ -78,7 +82,9 @@ static int fbk_polyexp(ofri_ctx *ctx, const float *src, float *dst5, int rows, i
 // arithmetic of k_fb_polyexp, whose rows and columns are clamped to the image: same bits as the two kernels.
 #define BP_TX 64
 #define BP_TY 16
-template <int N>
+// DMA (N + 1 a multiple of 4, rows of a multiple of 4 pixels on a 16-byte aligned base, at least a tile wide): the source
+// tile goes straight into LDS as 16-byte groups; tiles at the left and right border fill their mirror columns afterwards.
+template <int N, bool DMA = false>
 __global__ void __launch_bounds__(256)
 k_fb_blur3_polyexp(const float *__restrict__ src, float *__restrict__ dst, int H, int W, float k0, float k1, FbPoly c) {
     constexpr int SW = BP_TX + 2 * N + 2, SH = BP_TY + 2 * N + 2;     // source tile
@@ -93,7 +99,25 @@ k_fb_blur3_polyexp(const float *__restrict__ src, float *__restrict__ dst, int H
     float (*r1)[BWP] = reinterpret_cast<float (*)[BWP]>(pool + BP_TY * BWP);
     float (*r2)[BWP] = reinterpret_cast<float (*)[BWP]>(pool + 2 * BP_TY * BWP);
     const int bx = blockIdx.x * BP_TX, by = blockIdx.y * BP_TY, tid = threadIdx.x;
-    {   // all of a thread's loads are issued before the first one is used (one at a time they cost a memory latency each)
+    if (DMA) {
+        static_assert(!DMA || ((N + 1) % 4 == 0 && SW % 4 == 0 && (SH * (SW / 4)) % 64 == 0 && SH * 8 == 256), "whole 16-byte groups, whole wavefronts");
+        constexpr int NG = SH * (SW / 4), NK = (NG + 255) / 256;
+        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+#pragma unroll
+        for (int k = 0; k < NK; ++k)
+            if (256 * k + 64 * wv < NG) {
+                const int g = 256 * k + tid, r = g / (SW / 4), c = 4 * (g - r * (SW / 4));
+                const int y = fb_idx(by - N - 1 + r, H - 1), x = clampi(bx - N - 1 + c, 0, W - 4);
+                __builtin_amdgcn_global_load_lds((fb_gbl_void *)(src + (size_t)y * W + x), (fb_lds_void *)(pool + 4 * (256 * k + 64 * wv)), 16, 0, 0);
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (bx < N + 1 || bx + BP_TX + N + 1 > W) {
+            __syncthreads();
+            const int r = tid >> 3, j = tid & 7, xl = -1 - j, xr = W + j, cl = xl - (bx - N - 1), cr = xr - (bx - N - 1);
+            if (cl >= 0) S[r][cl] = S[r][fb_idx(xl, W - 1) - (bx - N - 1)];
+            if (cr < SW) S[r][cr] = S[r][fb_idx(xr, W - 1) - (bx - N - 1)];
+        }
+    } else {   // all of a thread's loads are issued before the first one is used (one at a time they cost a memory latency each)
         constexpr int NLD = (SH * SW + 255) / 256;
         float pre[NLD];
 #pragma unroll
@@ -205,46 +229,76 @@ k_fb_blur3_polyexp(const float *__restrict__ src, float *__restrict__ dst, int H
     }
 }
 
-// the five matrix entries of pixel (y, x) from its displacement (dx, dy) and the two expansions
+// the border attenuation of updateMatrices (.cl:330-333): one factor per side, multiplied in this order
+__device__ __forceinline__ float fb_border_scale(int x, int y, int H, int W) {
+    return c_fb_border[min(x, 5)] * c_fb_border[min(y, 5)] * c_fb_border[min(W - x - 1, 5)] * c_fb_border[min(H - y - 1, 5)];
+}
+
+// The five matrix entries of N pixels (y, x) from their displacements (dx, dy) and the two expansions; scale = the pixels'
+// border attenuation; pixels with on == false are computed on stand-in addresses and not stored.  Written without
+// branches and in phases over the N pixels (addresses, every load, arithmetic, stores), so that the loads of all N pixels
+// are in flight together: with a branch per pixel every pixel paid three memory latencies in turn.
+template <int N>
+__device__ __forceinline__ void fb_matrices_n(const int (&x)[N], const int (&y)[N], const float (&dx)[N], const float (&dy)[N],
+                                              const float (&scale)[N], const bool (&on)[N], const float *__restrict__ R0,
+                                              const float *__restrict__ R1, float *__restrict__ M, int H, int W) {
+    FB_PIXEL_CONTRACT
+    const size_t P = (size_t)H * W;
+    size_t o[N], q[N];
+    float fx[N], fy[N], c[N][5], g[N][5][4];
+    bool in[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        o[i] = on[i] ? (size_t)y[i] * W + x[i] : 0;
+        fx[i] = x[i] + dx[i]; fy[i] = y[i] + dy[i];
+        // convert_int(floor(.)): saturate so that absurd displacements stay "outside" instead of wrapping
+        const float flx = floorf(fx[i]), fly = floorf(fy[i]);
+        const int x1 = (int)fminf(fmaxf(flx, -1e9f), 1e9f), y1 = (int)fminf(fmaxf(fly, -1e9f), 1e9f);
+        fx[i] -= x1;
+        fy[i] -= y1;
+        in[i] = x1 >= 0 && y1 >= 0 && x1 < W - 1 && y1 < H - 1;
+        q[i] = in[i] ? (size_t)y1 * W + x1 : 0;
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const size_t d1 = in[i] ? 1 : 0, dW = in[i] ? (size_t)W : 0;          // outside: four reads of element 0, unused
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const float *p = R1 + k * P + q[i];
+            g[i][k][0] = p[0]; g[i][k][1] = p[d1]; g[i][k][2] = p[dW]; g[i][k][3] = p[dW + d1];
+            c[i][k] = R0[k * P + o[i]];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const float a00 = (1.f - fx[i]) * (1.f - fy[i]), a01 = fx[i] * (1.f - fy[i]), a10 = (1.f - fx[i]) * fy[i], a11 = fx[i] * fy[i];
+        float b[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) b[k] = a00 * g[i][k][0] + a01 * g[i][k][1] + a10 * g[i][k][2] + a11 * g[i][k][3];
+        float r2 = in[i] ? b[0] : 0.f, r3 = in[i] ? b[1] : 0.f;
+        const float r4in = (c[i][2] + b[2]) * 0.5f, r5in = (c[i][3] + b[3]) * 0.5f, r6in = (c[i][4] + b[4]) * 0.25f;
+        float r4 = in[i] ? r4in : c[i][2], r5 = in[i] ? r5in : c[i][3], r6 = in[i] ? r6in : c[i][4] * 0.5f;
+        r2 = (c[i][0] - r2) * 0.5f;
+        r3 = (c[i][1] - r3) * 0.5f;
+        r2 += r4 * dy[i] + r6 * dx[i];
+        r3 += r6 * dy[i] + r5 * dx[i];
+        r2 *= scale[i]; r3 *= scale[i]; r4 *= scale[i]; r5 *= scale[i]; r6 *= scale[i];
+        if (on[i]) {
+            M[o[i]] = r4 * r4 + r6 * r6;
+            M[P + o[i]] = (r4 + r5) * r6;
+            M[2 * P + o[i]] = r5 * r5 + r6 * r6;
+            M[3 * P + o[i]] = r4 * r2 + r6 * r3;
+            M[4 * P + o[i]] = r6 * r2 + r5 * r3;
+        }
+    }
+}
+
 __device__ __forceinline__ void fb_matrices_at(int x, int y, float dx, float dy, const float *__restrict__ R0,
                                                const float *__restrict__ R1, float *__restrict__ M, int H, int W) {
-    const size_t P = (size_t)H * W, o = (size_t)y * W + x;
-    float fx = x + dx, fy = y + dy;
-    // convert_int(floor(.)): saturate so that absurd displacements stay "outside" instead of wrapping
-    float flx = floorf(fx), fly = floorf(fy);
-    int x1 = (int)fminf(fmaxf(flx, -1e9f), 1e9f), y1 = (int)fminf(fmaxf(fly, -1e9f), 1e9f);
-    fx -= x1;
-    fy -= y1;
-    float r2, r3, r4, r5, r6;
-    if (x1 >= 0 && y1 >= 0 && x1 < W - 1 && y1 < H - 1) {
-        float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
-        size_t q = (size_t)y1 * W + x1;
-        const float *p = R1;
-        r2 = a00 * p[q] + a01 * p[q + 1] + a10 * p[q + W] + a11 * p[q + W + 1]; p += P;
-        r3 = a00 * p[q] + a01 * p[q + 1] + a10 * p[q + W] + a11 * p[q + W + 1]; p += P;
-        r4 = a00 * p[q] + a01 * p[q + 1] + a10 * p[q + W] + a11 * p[q + W + 1]; p += P;
-        r5 = a00 * p[q] + a01 * p[q + 1] + a10 * p[q + W] + a11 * p[q + W + 1]; p += P;
-        r6 = a00 * p[q] + a01 * p[q + 1] + a10 * p[q + W] + a11 * p[q + W + 1];
-        r4 = (R0[2 * P + o] + r4) * 0.5f;
-        r5 = (R0[3 * P + o] + r5) * 0.5f;
-        r6 = (R0[4 * P + o] + r6) * 0.25f;
-    } else {
-        r2 = r3 = 0.f;
-        r4 = R0[2 * P + o];
-        r5 = R0[3 * P + o];
-        r6 = R0[4 * P + o] * 0.5f;
-    }
-    r2 = (R0[o] - r2) * 0.5f;
-    r3 = (R0[P + o] - r3) * 0.5f;
-    r2 += r4 * dy + r6 * dx;
-    r3 += r6 * dy + r5 * dx;
-    float scale = c_fb_border[min(x, 5)] * c_fb_border[min(y, 5)] * c_fb_border[min(W - x - 1, 5)] * c_fb_border[min(H - y - 1, 5)];
-    r2 *= scale; r3 *= scale; r4 *= scale; r5 *= scale; r6 *= scale;
-    M[o] = r4 * r4 + r6 * r6;
-    M[P + o] = (r4 + r5) * r6;
-    M[2 * P + o] = r5 * r5 + r6 * r6;
-    M[3 * P + o] = r4 * r2 + r6 * r3;
-    M[4 * P + o] = r6 * r2 + r5 * r3;
+    const int xs[1] = {x}, ys[1] = {y};
+    const float dxs[1] = {dx}, dys[1] = {dy}, sc[1] = {fb_border_scale(x, y, H, W)};
+    const bool on[1] = {true};
+    fb_matrices_n<1>(xs, ys, dxs, dys, sc, on, R0, R1, M, H, W);
 }
 
 // ---- separable window filter on NP stacked planes (.cl:160-253, 350-406) -------------------------
@@ -332,6 +386,9 @@ k_fb_window(const float *__restrict__ src, float *__restrict__ dst, float *__res
 // UM (with FLOW): the matrices of the next iteration are made from the new displacement on the spot (updateMatrices,
 // a per-pixel step) and stored to Mnext; the displacement itself is stored only where flowx is given.
 #define BW_TY 32
+#ifndef FB_UM_NB
+#define FB_UM_NB 2
+#endif
 #ifndef FB_W16_WAVES
 #define FB_W16_WAVES 3
 #endif
@@ -340,40 +397,40 @@ k_fb_window(const float *__restrict__ src, float *__restrict__ dst, float *__res
 // while the current plane's horizontal pass runs.  Needs rows of a multiple of 4 pixels on a 16-byte aligned base and a
 // field at least as wide as a tile with its aprons; tiles at the left and right border fetch clamped 16-byte groups and
 // fill in the border columns from the tile's own interior afterwards.
-typedef __attribute__((address_space(3))) void fb_lds_void;
-typedef const __attribute__((address_space(1))) void fb_gbl_void;
 template <int NP, int MODE, bool FLOW, bool UM = false, bool DMA = false>
 __global__ void __launch_bounds__(256, DMA ? 4 : FB_W16_WAVES)
 k_fb_window16(const float *__restrict__ src, float *__restrict__ dst, float *__restrict__ flowx, float *__restrict__ flowy,
               int H, int W, FbTaps taps, int tiles_x, int ntiles, const float *__restrict__ R0 = nullptr,
               const float *__restrict__ R1 = nullptr, float *__restrict__ Mnext = nullptr) {
-    constexpr int KSH = 16, TW = BL_TX + 2 * KSH, TH = BW_TY + 2 * KSH;      // 96 x 64
+    constexpr int TY = BW_TY, KSH = 16, TW = BL_TX + 2 * KSH, TH = TY + 2 * KSH;      // 96 x 64
     constexpr int NLD = TH / 8 * 3;                                          // loads per thread and plane
-    constexpr int NR = BW_TY / 16;                                           // output rows per thread
+    constexpr int NR = TY / 16;                                           // output rows per thread
     __shared__ float tin[TH][TW];
-    __shared__ __attribute__((aligned(16))) float tv[BW_TY][TW];
+    __shared__ __attribute__((aligned(16))) float tv[TY][TW];
     // Workgroups go to the 8 XCDs round-robin by index and every XCD has its own L2: give each XCD a contiguous run of
     // tiles in raster order, so that the tiles whose 16-pixel aprons overlap are in flight on the same L2 (a tile reads
     // three times its own area; without this every apron came from memory again)
     const int b = blockIdx.x, q8 = ntiles >> 3, r8 = ntiles & 7, xcd = b & 7;
     const int t = xcd * q8 + (xcd < r8 ? xcd : r8) + (b >> 3);
-    const int bx = (t % tiles_x) * BL_TX, by = (t / tiles_x) * BW_TY, tid = threadIdx.x;
+    const int bx = (t % tiles_x) * BL_TX, by = (t / tiles_x) * TY, tid = threadIdx.x;
     const size_t P = (size_t)H * W;
     const int ly = tid >> 4, xg = tid & 15;                                  // horizontal pass: row (and row + 16), group of 4 columns
     float res[NP][NR][4] = {};
     // Register staging: this thread's samples of a plane's 64 x 96 source tile are rows (tid>>5) + 8s, columns
     // (tid&31) + 32q; all loads of a plane are issued together, and the next plane's are issued before the current
     // plane is filtered, so their latency hides behind the arithmetic.
-    // DMA: wavefront w fetches rows 16w .. 16w+15 of the tile as six loads of 16 bytes per lane.
-    constexpr int NOFF = DMA ? 6 : TH / 8 + 3;
+    // DMA: the tile's 16-byte groups in row-major order, 256 per round over the workgroup's lanes.
+    constexpr int NG = TH * (TW / 4), NK = (NG + 255) / 256;                 // 16-byte groups of the tile; loads per lane
+    static_assert(NG % 64 == 0, "whole wavefronts of 16-byte groups");
+    constexpr int NOFF = DMA ? NK : TH / 8 + 3;
     unsigned off[NOFF];                 // the launcher guarantees rows*cols < 2^32
     float pre[DMA ? 1 : NLD];
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool xborder = DMA && (bx < KSH || bx + BL_TX + KSH > W);
     if (DMA) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            const int e = wv * (16 * TW) + 256 * k + 4 * (tid & 63), r = e / TW, c = e - r * TW;
+        for (int k = 0; k < NK; ++k) {
+            const int g = min(256 * k + tid, NG - 1), r = g / (TW / 4), c = 4 * (g - r * (TW / 4));
             int y = by + r - KSH;
             y = MODE == 0 ? fb_idx(y, H - 1) : clampi(y, 0, H - 1);
             off[k] = (unsigned)y * (unsigned)W + (unsigned)clampi(bx + c - KSH, 0, W - 4);
@@ -394,8 +451,9 @@ k_fb_window16(const float *__restrict__ src, float *__restrict__ dst, float *__r
     auto fetch = [&](const float *sp) {
         if (DMA) {
 #pragma unroll
-            for (int k = 0; k < 6; ++k)
-                __builtin_amdgcn_global_load_lds((fb_gbl_void *)(sp + off[k]), (fb_lds_void *)(&tin[0][0] + wv * (16 * TW) + 256 * k), 16, 0, 0);
+            for (int k = 0; k < NK; ++k)
+                if (256 * k + 64 * wv < NG)     // the wavefront's 64 groups of this round lie inside the tile
+                    __builtin_amdgcn_global_load_lds((fb_gbl_void *)(sp + off[k]), (fb_lds_void *)(&tin[0][0] + 4 * (256 * k + 64 * wv)), 16, 0, 0);
         } else {
 #pragma unroll
             for (int e = 0; e < NLD; ++e) pre[e] = sp[off[e / 3] + off[TH / 8 + e % 3]];
@@ -410,7 +468,7 @@ k_fb_window16(const float *__restrict__ src, float *__restrict__ dst, float *__r
             if (xborder) {              // columns left of the field and right of it, from their mirror (clamp) columns
                 const int r = tid >> 2;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < 4 && r < TH; ++j) {
                     const int jj = 4 * (tid & 3) + j, xl = -1 - jj, xr = W + jj;
                     const int cl = xl - bx + KSH, cr = xr - bx + KSH;
                     if (cl >= 0) tin[r][cl] = tin[r][(MODE == 0 ? fb_idx(xl, W - 1) : 0) - bx + KSH];
@@ -426,9 +484,8 @@ k_fb_window16(const float *__restrict__ src, float *__restrict__ dst, float *__r
             __syncthreads();
             if (p + 1 < NP) fetch(src + (size_t)(p + 1) * P);
         }
-        static_assert((BW_TY / 4) * TW % 256 == 0, "the vertical pass divides evenly over the workgroup");
 #pragma unroll 1
-        for (int i = tid; i < (BW_TY / 4) * TW; i += 256) {
+        for (int i = tid; i < (TY / 4) * TW; i += 256) {
             const int rg = i / TW, col = i - rg * TW;
             float w[36];
 #pragma unroll
@@ -461,6 +518,9 @@ k_fb_window16(const float *__restrict__ src, float *__restrict__ dst, float *__r
                     float sm = c[KSH + k - i] + c[KSH + k + i];
                     acc += MODE == 0 ? sm * taps.k[i] : sm;
                 }
+                // the sum is made here: left alone the compiler moves a plane's whole horizontal pass past the following
+                // barriers to where the result is first used and keeps the row's window in scratch memory until then
+                asm volatile("" : "+v"(acc));
                 // res indexed by h would live in scratch memory (h is a loop variable): select into registers instead
 #pragma unroll
                 for (int hh = 0; hh < NR; ++hh) res[p][hh][k] = h == hh ? acc : res[p][hh][k];
@@ -473,8 +533,8 @@ k_fb_window16(const float *__restrict__ src, float *__restrict__ dst, float *__r
     const bool vec_ok = FLOW ? (UM || ((((size_t)flowx | (size_t)flowy) & 15) == 0)) : ((((size_t)dst) & 15) == 0);
     // UM: the displacements of the tile go through LDS (the source tile's space: every thread is past its last read of
     // it), so that the per-pixel step after them runs with one pixel per lane along rows (coalesced gathers and stores)
-    float (*tf)[BW_TY][BL_TX] = reinterpret_cast<float (*)[BW_TY][BL_TX]>(&tin[0][0]);
-    static_assert(sizeof(float) * 2 * BW_TY * BL_TX <= sizeof(float) * TH * TW, "the displacement tile fits in the source tile");
+    float (*tf)[TY][BL_TX] = reinterpret_cast<float (*)[TY][BL_TX]>(&tin[0][0]);
+    static_assert(sizeof(float) * 2 * TY * BL_TX <= sizeof(float) * TH * TW, "the displacement tile fits in the source tile");
     const bool vec4 = (W & 3) == 0 && vec_ok;     // a thread's four pixels are one aligned 16-byte group
 #pragma unroll
     for (int h = 0; h < NR; ++h) {
@@ -520,13 +580,25 @@ k_fb_window16(const float *__restrict__ src, float *__restrict__ dst, float *__r
     }
     if (FLOW && UM) {
         __syncthreads();
-#pragma unroll 2
-        for (int j = 0; j < BW_TY / 4; ++j) {
-            const int ry = (tid >> 6) + 4 * j, rx = tid & 63, y = by + ry, x = bx + rx;
-            if (y >= H || x >= W) continue;
-            const float ux = tf[0][ry][rx], uy = tf[1][ry][rx];
-            if (flowx) { flowx[(size_t)y * W + x] = ux; flowy[(size_t)y * W + x] = uy; }
-            fb_matrices_at(x, y, ux, uy, R0, R1, Mnext, H, W);
+        constexpr int NB = FB_UM_NB;                            // pixels of a thread in flight together
+        const int rx = tid & 63, x = bx + rx;
+        const bool xin = x < W;
+        const float bl = c_fb_border[min(xin ? x : 0, 5)], br = c_fb_border[min(xin ? W - x - 1 : 0, 5)];
+#pragma unroll 1
+        for (int j0 = 0; j0 < TY / 4; j0 += NB) {
+            int xs[NB], ys[NB];
+            float ux[NB], uy[NB], sc[NB];
+            bool on[NB];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int ry = __builtin_amdgcn_readfirstlane(tid >> 6) + 4 * (j0 + i), y = by + ry;     // one row per wavefront
+                const int yc = min(y, H - 1);
+                xs[i] = x; ys[i] = y; on[i] = xin && y < H;
+                ux[i] = tf[0][ry][rx]; uy[i] = tf[1][ry][rx];
+                sc[i] = bl * c_fb_border[min(yc, 5)] * br * c_fb_border[min(H - yc - 1, 5)];
+                if (flowx && on[i]) { flowx[(size_t)y * W + x] = ux[i]; flowy[(size_t)y * W + x] = uy[i]; }
+            }
+            fb_matrices_n<NB>(xs, ys, ux, uy, sc, on, R0, R1, Mnext, H, W);
         }
     }
 }
@@ -658,6 +730,7 @@ static int fbk_blur_polyexp(ofri_ctx *ctx, const float *src, float *dst5, int ro
     memcpy(c.ig, ig_host, 4 * sizeof(float));
     dim3 g(ceil_div(cols, BP_TX), ceil_div(rows, BP_TY));
     if (polyN == 5) k_fb_blur3_polyexp<5><<<g, 256, 0, ctx->stream>>>(src, dst5, rows, cols, blur_half_taps_host[0], blur_half_taps_host[1], c);
+    else if (fb_window_dma_ok(src, cols)) k_fb_blur3_polyexp<7, true><<<g, 256, 0, ctx->stream>>>(src, dst5, rows, cols, blur_half_taps_host[0], blur_half_taps_host[1], c);
     else k_fb_blur3_polyexp<7><<<g, 256, 0, ctx->stream>>>(src, dst5, rows, cols, blur_half_taps_host[0], blur_half_taps_host[1], c);
     OFRI_LAUNCH_CHECK();
     return OFRI_OK;

@@ -689,7 +689,7 @@ def test_farneback_kernels_vs_oracle(ctx, shape, fb_mode):
     same(ux, uxo, "updateFlow x"); same(uy, uyo, "updateFlow y")
 
 
-@pytest.mark.parametrize("shape", [(1, 1), (3, 5), (16, 64), (17, 65), (70, 130), (5, 300), (200, 9), (128, 256)])
+@pytest.mark.parametrize("shape", [(1, 1), (3, 5), (16, 64), (17, 65), (70, 130), (5, 300), (200, 9), (128, 256), (40, 68), (33, 1028)])
 @pytest.mark.parametrize("polyN,ksh", [(7, 1), (5, 1), (7, 2)])
 def test_farneback_blur_polyexp_equals_its_steps(ctx, shape, polyN, ksh, fb_mode):
     """Pre-blur and polynomial expansion in one call: the bits of ofri_fb_blur followed by ofri_fb_polyexp."""
