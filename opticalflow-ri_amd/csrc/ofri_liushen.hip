@@ -397,7 +397,7 @@ template <int NL, int PX> struct LtCfg {
     static constexpr int NS = NL / 2;                          // pipeline stages
     static constexpr int LN = LT_RX / PX;                      // lanes of a stage
     static constexpr int LAG = 3 * NS;                         // the last stage's second sweep runs this many rows behind the loader
-    static constexpr int CR = LAG + 1;                         // coefficient ring rows: a stage reads rows rA and rA-1
+    static constexpr int CR = LAG + 1;                         // coefficient ring rows: the last stage reads a row LAG - 1 steps after the loader wrote it
     static constexpr int STAGE_THREADS = (NS * LN + 63) / 64 * 64;
     static constexpr int THREADS = STAGE_THREADS + 64;         // + the loader wavefront
     static constexpr int LDS = CR * 8 * LT_RX * 4 + NS * 2 * 2 * LT_RX * 4;
@@ -480,6 +480,7 @@ __device__ __forceinline__ LtRow<PX> lt_sweep(const LtRow<PX> &a, const LtRow<PX
 template <int PX> struct LtStage {   // registers of one pipeline stage (one lane)
     LtRow<PX> in0, in1;              // input rows rA-1, rA
     LtRow<PX> mid0, mid1;            // rows rA-2, rA-1 of the stage's first sweep
+    LtCoef<PX> gprev;                // coefficients of row rA-1 (read from the ring one step ago)
     float au0, av0, au1, av1;        // squared change of the stage's first / second sweep over this lane's stored pixels
     int rA;                          // row the first sweep produces at this step
     int cslot;                       // coefficient ring slot of row rA
@@ -494,17 +495,14 @@ __device__ __forceinline__ void lt_stage_step(LtStage<PX> &st, float (&ring)[LtC
     LtRow<PX> nw;                                                       // newest input row rA+1
     lt_read<PX>(&ring[stage][(st.rA + 1) & 1][0][l * PX], nw.u);
     lt_read<PX>(&ring[stage][(st.rA + 1) & 1][1][l * PX], nw.v);
-    LtCoef<PX> g, gprev;                                                // coefficients of rows rA and rA-1 (the slot before)
-    const int pslot = st.cslot == 0 ? CR - 1 : st.cslot - 1;
+    LtCoef<PX> g;                                                       // coefficients of row rA
 #pragma unroll
     for (int i = 0; i < 8; ++i) lt_read<PX>(&coef[st.cslot][i][l * PX], g.p[i]);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) lt_read<PX>(&coef[pslot][i][l * PX], gprev.p[i]);
     st.cslot = st.cslot + 1 == CR ? 0 : st.cslot + 1;
     const int rA = st.rA, rB = st.rA - 1;
     const LtRow<PX> mid2 = lt_sweep<PX, EDGE, FULL>(st.in0, st.in1, nw, g, h, rA == 0, rA == H - 1, isL, isR, passA,
                                                     own_lane && rA >= ya && rA < yb, st.au0, st.av0);          // row rA of the first sweep
-    const LtRow<PX> out = lt_sweep<PX, EDGE, FULL>(st.mid0, st.mid1, mid2, gprev, h, rB == 0, rB == H - 1, isL, isR, passB,
+    const LtRow<PX> out = lt_sweep<PX, EDGE, FULL>(st.mid0, st.mid1, mid2, st.gprev, h, rB == 0, rB == H - 1, isL, isR, passB,
                                                    own_lane && rB >= ya && rB < yb, st.au1, st.av1);           // row rA-1 of the second sweep
     if (stage < NS - 1) {
         lt_write<PX>(&ring[stage + 1][rB & 1][0][l * PX], out.u);
@@ -515,6 +513,7 @@ __device__ __forceinline__ void lt_stage_step(LtStage<PX> &st, float (&ring)[LtC
     }
     st.in0 = st.in1; st.in1 = nw;
     st.mid0 = st.mid1; st.mid1 = mid2;
+    st.gprev = g;
     ++st.rA;
 }
 
@@ -611,6 +610,10 @@ k_ls_stream(LsBufs bufs, int src, int dst, const float *__restrict__ coefs, long
             st.mid0.u[q] = st.mid0.v[q] = st.mid1.u[q] = st.mid1.v[q] = 0.f;
         }
         st.au0 = st.av0 = st.au1 = st.av1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int q = 0; q < PX; ++q) st.gprev.p[i][q] = 0.f;
         st.rA = rho0 - 2 - 3 * stage;
         st.cslot = (st.rA + 64 * CR) % CR;
         const bool passA = 2 * stage >= T, passB = 2 * stage + 1 >= T;
@@ -619,20 +622,20 @@ k_ls_stream(LsBufs bufs, int src, int dst, const float *__restrict__ coefs, long
         const bool own_lane = store_lane && live;
         const bool edge = x0 < 0 || x0 + LT_RX > W;
         const bool isL = lane_x == 0, isR = lane_x + PX == W;
-#define LT_STEP(EDGE_)                                                                                                \
+#define LT_STEP(EDGE_, U_)                                                                                            \
     {                                                                                                                 \
-        const int ro = rho0 - LAG + t;                    /* row the last stage finishes at this step */              \
+        const int ro = rho0 - LAG + t + (U_);             /* row the last stage finishes at this step */              \
         lt_stage_step<NL, PX, FULL, EDGE_>(st, ring, coef, stage, live, l, passA, passB, store_lane, own_lane, isL, isR, lane_x, \
                                            un + (long long)ro * W, vn + (long long)ro * W, h, H, ya, yb);           \
         __syncthreads();                                                                                              \
     }
-        // one step per round: spelling out six steps (so that the row registers rotate by renaming, as the Horn-Schunck
-        // pipeline does) makes the compiler keep over 300 registers live here
+        // two steps per round (nsteps is a multiple of six): the row registers take turns by renaming instead of moves.
+        // Spelling out six steps, as the Horn-Schunck pipeline does, makes the compiler keep over 300 registers live here
         OfriPrioState ps = ofri_prio_begin(pr, nsteps, j);
         if (edge) {
-            for (int t = 0; t < nsteps; ++t) { ofri_prio_turn(t, pr, ps); LT_STEP(true) }
+            for (int t = 0; t < nsteps; t += 2) { ofri_prio_turn(t, pr, ps); LT_STEP(true, 0) LT_STEP(true, 1) }
         } else {
-            for (int t = 0; t < nsteps; ++t) { ofri_prio_turn(t, pr, ps); LT_STEP(false) }
+            for (int t = 0; t < nsteps; t += 2) { ofri_prio_turn(t, pr, ps); LT_STEP(false, 0) LT_STEP(false, 1) }
         }
 #undef LT_STEP
         if (!REDO) {
