@@ -405,7 +405,7 @@ k_fb_window16(const float *__restrict__ src, float *__restrict__ dst, float *__r
     constexpr int TY = BW_TY, KSH = 16, TW = BL_TX + 2 * KSH, TH = TY + 2 * KSH;      // 96 x 64
     constexpr int NLD = TH / 8 * 3;                                          // loads per thread and plane
     constexpr int NR = TY / 16;                                           // output rows per thread
-    __shared__ float tin[TH][TW];
+    __shared__ __attribute__((aligned(16))) float tin[TH][TW];     // 16-byte groups land here by LDS-DMA
     __shared__ __attribute__((aligned(16))) float tv[TY][TW];
     // Workgroups go to the 8 XCDs round-robin by index and every XCD has its own L2: give each XCD a contiguous run of
     // tiles in raster order, so that the tiles whose 16-pixel aprons overlap are in flight on the same L2 (a tile reads
