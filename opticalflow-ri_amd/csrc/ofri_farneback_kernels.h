@@ -90,8 +90,8 @@ k_fb_blur3_polyexp(const float *__restrict__ src, float *__restrict__ dst, int H
     constexpr int SW = BP_TX + 2 * N + 2, SH = BP_TY + 2 * N + 2;     // source tile
     constexpr int BW = BP_TX + 2 * N, BH = BP_TY + 2 * N;             // blurred tile: image rows by-N .., columns bx-N ..
     constexpr int NQ = (4 + 2 * N + 3) / 4, BWP = (BP_TX + 4 * NQ - 4 + 3) & ~3;   // 16-byte groups of a window; row pitch of r0, r1, r2
-    __shared__ __attribute__((aligned(16))) float pool[SH * SW + BH * SW];   // source tile + vertical pass; later r0, r1, r2
-    __shared__ float B[BH][BW];
+    __shared__ __attribute__((aligned(16))) float pool[SH * SW + BH * SW + 4];   // source tile + vertical pass (+ the 16 bytes the last task of the second blur pass reads beyond it); later r0, r1, r2
+    __shared__ __attribute__((aligned(16))) float B[BH][SW];            // blurred tile (BW columns used)
     static_assert(3 * BP_TY * BWP <= SH * SW + BH * SW && BWP >= BW, "the three partial-sum planes fit where the blur's tiles were");
     float (*S)[SW] = reinterpret_cast<float (*)[SW]>(pool);
     float (*V)[SW] = reinterpret_cast<float (*)[SW]>(pool + SH * SW);
@@ -133,18 +133,32 @@ k_fb_blur3_polyexp(const float *__restrict__ src, float *__restrict__ dst, int H
         }
     }
     __syncthreads();
-    for (int i = tid; i < BH * SW; i += 256) {
-        const int ly = i / SW, lx = i - ly * SW;
-        float acc = S[ly + 1][lx] * k0;
-        acc += (S[ly][lx] + S[ly + 2][lx]) * k1;
-        V[ly][lx] = acc;
+    // both blur passes four columns per task (16-byte LDS accesses; the per-element form spent most of its instructions
+    // on index arithmetic)
+    static_assert(SW % 4 == 0 && (SH * SW) % 4 == 0, "rows of whole 16-byte groups");
+    for (int i = tid; i < BH * (SW / 4); i += 256) {
+        const int ly = i / (SW / 4), lx = 4 * (i - ly * (SW / 4));
+        const float4 s0 = *reinterpret_cast<const float4 *>(&S[ly][lx]), s1 = *reinterpret_cast<const float4 *>(&S[ly + 1][lx]);
+        const float4 s2 = *reinterpret_cast<const float4 *>(&S[ly + 2][lx]);
+        float4 acc;
+        acc.x = s1.x * k0; acc.x += (s0.x + s2.x) * k1;
+        acc.y = s1.y * k0; acc.y += (s0.y + s2.y) * k1;
+        acc.z = s1.z * k0; acc.z += (s0.z + s2.z) * k1;
+        acc.w = s1.w * k0; acc.w += (s0.w + s2.w) * k1;
+        *reinterpret_cast<float4 *>(&V[ly][lx]) = acc;
     }
     __syncthreads();
-    for (int i = tid; i < BH * BW; i += 256) {
-        const int ly = i / BW, lx = i - ly * BW;
-        float acc = V[ly][lx + 1] * k0;
-        acc += (V[ly][lx] + V[ly][lx + 2]) * k1;
-        B[ly][lx] = acc;
+    for (int i = tid; i < BH * (SW / 4); i += 256) {
+        const int ly = i / (SW / 4), lx = 4 * (i - ly * (SW / 4));
+        // columns lx .. lx + 5 of the row; the last task of a row reads into the next row (the last row: into the pool's
+        // spare 16 bytes) for outputs beyond column BW - 1, which nothing reads
+        const float4 v0 = *reinterpret_cast<const float4 *>(&V[ly][lx]), v1 = *reinterpret_cast<const float4 *>(&V[ly][lx] + 4);
+        float4 acc;
+        acc.x = v0.y * k0; acc.x += (v0.x + v0.z) * k1;
+        acc.y = v0.z * k0; acc.y += (v0.y + v0.w) * k1;
+        acc.z = v0.w * k0; acc.z += (v0.z + v1.x) * k1;
+        acc.w = v1.x * k0; acc.w += (v0.w + v1.y) * k1;
+        *reinterpret_cast<float4 *>(&B[ly][lx]) = acc;
     }
     __syncthreads();
     // expansion, vertical pass; rows clamped (:98-99), columns clamped (:89).  Entries of B outside the image are never read.
