@@ -497,7 +497,9 @@ def main():
         lanes = []
         for k in range(3):
             c = ctx if k == 0 else _ofri.Context(dev)
+            c.set_share(2)              # the lanes' launches take half the row chunks each (what piv_batch.flow_lanes sets)
             pk = FlowPlan((H, W), 3.4, lambda: HSOpticalFlowAlgoAdapter([21, 45], args.niter), pyramidalLevels=2, ctx=c, **opt_args)
+            c.set_share(1)              # the captured graph keeps its launch shapes
             pk.load(*((im0, im1) if k == 0 else synth_piv(H, W, seed=100 + k)))
             c.sync()
             lanes.append((c, pk))

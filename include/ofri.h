@@ -132,6 +132,14 @@ int ofri_hs_derivs(ofri_ctx *ctx, const float *first, const float *second,
 int ofri_hs_iterate(ofri_ctx *ctx, float *U, float *V, const float *fx, const float *fy,
                     const float *ft, float alpha, int niter, int rows, int cols);
 int ofri_hs_set_fuse(ofri_ctx *ctx, int sweeps_per_launch);
+/* No reference counterpart: a hint for callers that keep several frame pairs in flight on one GPU, each on a context
+ * of its own (piv_batch.flow_lanes).  The row-streaming pipelines (Horn-Schunck, Liu-Shen) cut a field into as many row
+ * chunks as fill the GPU once; every chunk recomputes the rows above it that its sweeps depend on (30 rows for 12
+ * Horn-Schunck sweeps), which is the price of a short latency for one pair.  With this hint a launch takes 1/contexts
+ * of those chunks and leaves the rest of the GPU to the other contexts' launches: less is recomputed and more pairs
+ * finish per second (three contexts at 2048 x 2048: best with 2, worse than the default from 4 on).  Same bits.
+ * Default 1. */
+int ofri_set_share(ofri_ctx *ctx, int contexts);
 /* Timing of the sweep launches, for roofline reports: while enabled, every ofri_hs_iterate call
  * brackets its sweep launches with two HIP events on the context's stream and appends a record.
  * ofri_prof_read syncs on record idx and returns its elapsed time, the number of kernel launches and

@@ -61,6 +61,7 @@ _PROTOS = {
     "ofri_hs_derivs": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i], _i),
     "ofri_hs_iterate": ([_vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i], _i),
     "ofri_hs_set_fuse": ([_vp, _i], _i),
+    "ofri_set_share": ([_vp, _i], _i),
     "ofri_prof_enable": ([_vp, _i], _i),
     "ofri_prof_count": ([_vp, C.POINTER(_i)], _i),
     "ofri_prof_read": ([_vp, _i, C.POINTER(_f), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)], _i),
@@ -230,6 +231,11 @@ class Context(object):
 
     def set_hs_fuse(self, t):
         check(lib().ofri_hs_set_fuse(self._h, int(t)))
+
+    def set_share(self, contexts):
+        """Tell the row-streaming pipelines that ``contexts`` contexts keep this GPU busy together: longer row chunks,
+        less recomputation, longer latency of a single pair (same bits)."""
+        check(lib().ofri_set_share(self._h, int(contexts)))
 
     def set_fb_mode(self, mode):
         check(lib().ofri_fb_set_mode(self._h, int(mode)))

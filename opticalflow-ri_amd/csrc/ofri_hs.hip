@@ -169,6 +169,13 @@ int ofri_hs_fused_launch_pitched(ofri_ctx *ctx, const float *su, const float *sv
                                  const float *fy, const float *ft, int T, int H, int W, int pin, int pc, int pout,
                                  bool accumulate);
 
+extern "C" int ofri_set_share(ofri_ctx *ctx, int contexts) {
+    OFRI_REQUIRE(ctx, "null context");
+    OFRI_REQUIRE(contexts >= 1 && contexts <= 16, "contexts sharing the GPU: 1..16");
+    ctx->share = contexts;
+    return OFRI_OK;
+}
+
 extern "C" int ofri_hs_set_fuse(ofri_ctx *ctx, int sweeps_per_launch) {
     OFRI_REQUIRE(ctx, "null context");
     OFRI_REQUIRE(sweeps_per_launch >= -1 && sweeps_per_launch <= 64, "sweeps_per_launch out of range");

@@ -454,6 +454,7 @@ static void sl_launch(ofri_ctx *ctx, const SlPlanes &in, float *uo, float *vo, i
     int nchunks = Cfg::PER_CU * ofri_ctx_ncu(ctx) / tiles_x;
     if (nchunks < 1) nchunks = 1;
     if (ceil_div(H, nchunks) < Cfg::MIN_CHUNK && Cfg::PER_CU > 2) nchunks = max(1, (Cfg::PER_CU - 1) * ofri_ctx_ncu(ctx) / tiles_x);
+    nchunks = max(1, nchunks / ctx->share);           // other contexts fill the rest of the GPU (ofri_set_share)
     const int chunk_rows = ceil_div(H, nchunks);
     nchunks = ceil_div(H, chunk_rows);
     const int grid = tiles_x * nchunks, thr = Cfg::THREADS;

@@ -15,6 +15,7 @@ struct ofri_ctx {
     hipStream_t stream = nullptr;
     bool owns_stream = false;
     int hs_fuse = 0;                                   // sweeps per launch, 0 = automatic
+    int share = 1;                                     // contexts whose launches overlap on this GPU (ofri_set_share)
     int fb_mode = 0;                                   // Farneback: 0 fast (fused multiply-adds), -1 exact (separately rounded)
     int lk_mode = 0;                                   // dense LK: 0 fast (tile kernel where it applies), -1 exact
     int ls_mode = 0;                                   // Liu-Shen: 0 automatic, 1 one sweep per launch, 6 / 8 pipeline depth, -1 exact

@@ -660,7 +660,7 @@ k_ls_stream(LsBufs bufs, int src, int dst, const float *__restrict__ coefs, long
 template <int NL, int PX>
 static void lt_grid(ofri_ctx *ctx, int H, int W, int *tiles_x, int *chunk_rows, int *tiles) {
     *tiles_x = ceil_div(W, LT_OX);
-    int nchunks = LtCfg<NL, PX>::PER_CU * ofri_ctx_ncu(ctx) / *tiles_x;
+    int nchunks = LtCfg<NL, PX>::PER_CU * ofri_ctx_ncu(ctx) / *tiles_x / ctx->share;      // share: other contexts fill the rest of the GPU
     if (nchunks < 1) nchunks = 1;
     int cr = ceil_div(H, nchunks);
     if (cr < 16) cr = H < 16 ? H : 16;          // shorter chunks are mostly fill; longer ones leave CUs idle (24 to 64 rows measured no better)

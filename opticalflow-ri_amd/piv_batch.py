@@ -113,11 +113,15 @@ def torch_context(device=0, make_current=True):
 def flow_lanes(n, make_flow, device=0):
     """``n`` independent (ctx, flow_fn) lanes on one GPU for run_batch(lanes=...): each its own stream, pool and captured
     graph, so that n pairs are in flight at once (the launches of one pair leave gaps and tails that another pair's fill;
-    2048 x 2048 Horn-Schunck + Liu-Shen: 3 lanes give 1.26 times the pairs per second of one).  ``make_flow(ctx)``
+    2048 x 2048 Horn-Schunck + Liu-Shen: 3 lanes give 1.4 times the pairs per second of one).  ``make_flow(ctx)``
     returns the lane's flow function (e.g. lambda c: hs_liushen_flow(c, shape)).  The first lane's stream is current."""
     out = []
     for i in range(max(1, int(n))):
         ctx, _ = torch_context(device, make_current=(i == 0))
+        # half as many row chunks per launch once another lane fills the rest of the GPU (64 pairs of 2048 x 2048 on three
+        # lanes: 2670 -> 2955 Mpix/s; a third of the chunks 2890, a quarter 2670).  Before make_flow: a captured graph
+        # keeps the launch shapes of its capture
+        ctx.set_share(2 if int(n) >= 2 else 1)
         out.append((ctx, make_flow(ctx)))
     return out
 

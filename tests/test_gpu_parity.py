@@ -284,6 +284,31 @@ def test_hs_whole_level_equals_its_steps(ctx, shape, ksize, warp, nit):
     np.testing.assert_array_equal(Uf.numpy(), want[0]); np.testing.assert_array_equal(Vf.numpy(), want[1])
 
 
+@pytest.mark.parametrize("shape", [(2048, 2048), (1030, 2052)])
+def test_pipelines_give_the_same_bits_when_contexts_share_the_gpu(ctx, shape):
+    """ofri_set_share: fewer, longer row chunks in the Horn-Schunck and Liu-Shen pipelines, same results."""
+    import _ofri
+    from PhysicsBasedOpticalFlowLiuShen import liushen_device
+    lib = _ofri.lib()
+    H, W = shape
+    rng = np.random.default_rng(H + W)
+    pl = [rng.standard_normal(shape).astype(np.float32) for _ in range(5)]
+    a = rng.uniform(0, 255, shape).astype(np.float32); b = np.roll(a, 1, axis=1)
+    out = []
+    try:
+        for share in (1, 3):
+            ctx.set_share(share)
+            d = [ctx.upload(p) for p in pl]
+            _ofri.check(lib.ofri_hs_iterate(ctx.handle, d[0].ptr, d[1].ptr, d[2].ptr, d[3].ptr, d[4].ptr, 10.0, 40, H, W))
+            U, V = liushen_device(ctx.upload(a), ctx.upload(b), 5.0, ctx.upload(pl[0]), ctx.upload(pl[1]), want_error=False)[:2]
+            out.append([d[0].numpy(), d[1].numpy(), U.numpy(), V.numpy()])
+    finally:
+        ctx.set_share(1)
+    assert lib.ofri_set_share(ctx.handle, 0) != 0
+    for x, y, what in zip(out[0], out[1], ("HS u", "HS v", "LS u", "LS v")):
+        assert x.tobytes() == y.tobytes(), what
+
+
 def test_hs_zero_iterations_returns_input(ctx):
     import HornSchunck as H
     rng = np.random.default_rng(1)
