@@ -18,7 +18,7 @@ timeout -s KILL 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format cs
 timeout -s KILL 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/paths_write -o p -- python3 $P --reps 2 --cfg3-size 0 > /dev/null
 timeout -s KILL 200 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $O/paths_sq -o p -- python3 $P --reps 2 --cfg3-size 0 > /dev/null
 cd $GRAFT_REPO_ROOT
-timeout -k 10 400 python3 bench.py > $O/bench_default.json
+timeout -k 10 400 python3 bench.py --steps 20 --warmup 5 > $O/bench_default.json
 timeout -k 10 300 python3 bench_paths.py --reps 5 > $O/bench_paths.txt
 timeout -k 10 200 python3 bench.py --no-cpu-baseline --with-transfer > $O/bench_with_transfer.json
 timeout -k 10 300 python3 bench.py --batch 64 --steps 2 --warmup 1 > $O/bench_batch64.json
