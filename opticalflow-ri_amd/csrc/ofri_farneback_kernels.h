@@ -409,7 +409,7 @@ k_fb_window(const float *__restrict__ src, float *__restrict__ dst, float *__res
 // DMA: the source tiles go from memory straight into LDS (16-byte LDS-DMA loads: no staging registers, no LDS store
 // instructions), which brings the kernel under 128 registers, four workgroups per CU; the next plane's tile is fetched
 // while the current plane's horizontal pass runs.  Needs rows of a multiple of 4 pixels on a 16-byte aligned base and a
-// field at least as wide as a tile with its aprons; tiles at the left and right border fetch clamped 16-byte groups and
+// field at least one tile wide (fb_window_dma_ok); tiles at the left and right border fetch clamped 16-byte groups and
 // fill in the border columns from the tile's own interior afterwards.
 template <int NP, int MODE, bool FLOW, bool UM = false, bool DMA = false>
 __global__ void __launch_bounds__(256, DMA ? 4 : FB_W16_WAVES)
