@@ -12,6 +12,12 @@ independent, so the timed path has no exchange between ranks (barrier before and
 
     python bench.py --gpus 1 --steps 10 --warmup 2
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...          # no launcher: this process starts the N ranks itself and relays rank 0's line
+
+Started with ``--gpus N`` (N > 1) and no WORLD_SIZE in the environment, the process never touches the GPU: it checks that
+N devices are visible (exit code 2 with a message otherwise; ``--same-device`` puts all ranks on GPU 0 for rehearsals),
+starts N fresh rank processes with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, relays rank 0's JSON line and exits
+non-zero if any rank fails.
 
 ``--batch P`` measures the batch configuration instead: P independent 2048x2048 pairs (``--size``), Horn-Schunck
 plus Liu-Shen per pair, sharded in contiguous blocks over the ranks, flow fields gathered to rank 0 per chunk
@@ -29,7 +35,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "opticalflow-ri_amd")]
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak
-HBM_COPY_GBS = 4700.0          # what a device-to-device copy of 4 GiB sustains on the box (read + write; tools/hbm_copy_rate.py)
+HBM_COPY_GBS = 4700.0          # what a device-to-device copy of 4 GiB sustains on the box (read + write; tools/hbm_copy_rate.py);
+                               # reported beside the figures, not the yardstick of "memory-bound" (a streaming kernel moves more)
 HS_BYTES_PER_PX_SWEEP = 28.0   # one Jacobi sweep: read U,V and three coefficient planes + write U,V, float32
 VALU_LANE_OPS_PER_S = 256 * 4 * 16 * 2.4e9      # 256 CUs x 4 SIMDs x one wavefront instruction per 4 cycles (the rate of fused
                                                 # multiply-adds, tools/valu_operands.hip) x 2.4 GHz, one operation per lane
@@ -66,6 +73,8 @@ def parse():
     ap.add_argument("--no-in-flight", action="store_true", help="skip the three-pairs-in-flight throughput figure")
     ap.add_argument("--batch", type=int, default=0, help="total number of pairs of the batch configuration (512 on 8 GPUs); 0 = headline")
     ap.add_argument("--chunk", type=int, default=8, help="with --batch: pairs per gather")
+    ap.add_argument("--launch-check", action="store_true", help="ranks only rendezvous (process group, one all-reduce) and rank 0 "
+                    "prints what it saw: checks the launcher and the argument path without any GPU work")
     ap.add_argument("--distinct", type=int, default=4, help="with --batch: distinct synthetic pairs generated per rank (cycled; "
                     "rendering one 2048x2048 pair takes 0.5 s of host time)")
     a = ap.parse_args()
@@ -108,11 +117,12 @@ def cpu_baseline(niter, all_cores=True, n=2048):
     times = sorted(_cpu_pair((n, niter, k)) for k in range(3))
     med = times[1]
     t_full = _cpu_pair((4096, niter, 0))
-    out = {"value": n * n / med / 1e6, "unit": "Mpix/s", "cores": 1, "kind": "port",
+    out = {"value": 4096 * 4096 / t_full / 1e6, "unit": "Mpix/s", "cores": 1, "kind": "port",
            "cpu_model": _cpu_model(), "nproc": os.cpu_count(),
-           "runs_s": [round(t, 3) for t in times], "value_4096_single_run": 4096 * 4096 / t_full / 1e6,
-           "sample": "same 2-level HS pipeline (Fs3.4, alphas [21,45], %d sweeps/level), NumPy/SciPy single thread: median of "
-                     "3 runs on %dx%d synthetic pairs (%.1f s each), plus one 4096x4096 pair (%.1f s)" % (niter, n, n, med, t_full)}
+           "runs_s": [round(t, 3) for t in times], "value_%d_median_of_3" % n: n * n / med / 1e6,
+           "sample": "same 2-level HS pipeline (Fs3.4, alphas [21,45], %d sweeps/level), NumPy/SciPy single thread: one pair at the "
+                     "metric's own size, 4096x4096 (%.1f s; `value`), beside the median of 3 runs on %dx%d synthetic pairs "
+                     "(%.1f s each)" % (niter, t_full, n, n, med)}
     if all_cores:
         try:
             import multiprocessing as mp
@@ -157,11 +167,13 @@ def one_sweep_roofline(ctx, H, W, launches=20):
         ctx.set_hs_fuse(0)
     ms = sum(r[0] for r in recs) / max(1, sum(r[1] for r in recs))
     gbs = HS_BYTES_PER_PX_SWEEP * H * W / (ms * 1e-3) / 1e9
+    traffic = _committed("pmc_traffic.json").get("k_hs_sweep@%dx%d" % (H, W))
     return {"kernel": "k_hs_sweep_vec4@%dx%d" % (H, W), "bound": "hbm", "launch_ms": ms, "achieved": gbs,
-            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "launches_timed": launches}
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "launches_timed": launches,
+            "traffic": traffic, "traffic_GBs": (traffic / (ms * 1e-3) / 1e9) if traffic else None}
 
 
-def roofline_block(recs, H, W, steps, ms_per_step):
+def roofline_block(recs, H, W, steps, ms_per_step, streaming=None):
     """Dominant kernel = the Jacobi sweep launches of the full-resolution level.  A Horn-Schunck call may use several
     kernels there (row-streaming pipeline for the multiples of 12 sweeps, a deeper launch or the tile kernel for the
     rest); the one with the largest share of the time is reported."""
@@ -192,11 +204,18 @@ def roofline_block(recs, H, W, steps, ms_per_step):
     sq = _committed("pmc_sq.json").get(key)                         # issue fractions from the committed SQ pass
     useful = HS_OPS_PER_PX_SWEEP * H * W * spl / VALU_LANE_OPS_PER_S * 1e3          # ms of vector issue the sweeps need
     hbm_meas = (traffic / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None
-    # A blocked launch is bound by what the measurements show: memory once its counted traffic moves at the rate a plain
-    # copy sustains (a launch of a third of the sweeps then takes the same time), vector issue below that.
-    mem_bound = hbm_meas is not None and hbm_meas * HBM_PEAK_GBS >= 0.85 * HBM_COPY_GBS
+    # A blocked launch is called memory-bound only when its counted traffic moves at (85 % of) the rate the HBM-bound
+    # one-sweep kernel sustains on the same field in this very run (`streaming`: counted bytes over its measured launch
+    # time, about 6.2 TB/s); below that the limit is on the chip: instruction issue, whose measured fractions
+    # (simd_any_issue, simd_valu_issue) stand beside the label.
+    stream_gbs = (streaming or {}).get("traffic_GBs")
+    mem_bound = hbm_meas is not None and stream_gbs is not None and hbm_meas * HBM_PEAK_GBS >= 0.85 * stream_gbs
     block = {
-        "bound": ("hbm" if mem_bound else "valu-issue") if blocked else "hbm",
+        "bound": ("hbm" if mem_bound else "issue") if blocked else "hbm",
+        "bound_basis": None if not blocked else
+        "counted traffic moves at %s GB/s against %s GB/s of the one-sweep kernel in the same run; SIMD issue slots taken: %s (vector: %s)" % (
+            ("%.0f" % (hbm_meas * HBM_PEAK_GBS)) if hbm_meas is not None else "?", ("%.0f" % stream_gbs) if stream_gbs else "?",
+            (sq or {}).get("simd_any_issue", "?"), (sq or {}).get("simd_valu_issue", "?")),
         "kernel": key, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
         "traffic": traffic, "launch_ms": launch_ms, "launches_timed": launches, "sweeps_per_launch": spl,
         "algorithmic_bytes_per_launch": alg_launch,
@@ -282,6 +301,77 @@ def run_batch_config(args, rank, world, local, dist, torch):
     }
 
 
+# ------------------------------------------------------------------------------------------ own launcher
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def visible_gpus():
+    """Number of GPUs this process could use, without initialising any (the parent of the ranks must stay off the GPU)."""
+    import torch
+    return int(torch.cuda.device_count())
+
+
+def launch_ranks(args, argv):
+    """``--gpus N`` without a launcher: start N rank processes (one per GPU), relay rank 0's standard output, return the
+    exit code (the first failing rank's; the other ranks are then terminated by their process ids)."""
+    import subprocess
+    n = args.gpus
+    if not args.same_device and not args.launch_check:
+        have = visible_gpus()
+        if have < n:
+            sys.stderr.write("bench.py: --gpus %d but %d GPU(s) visible; nothing measured (use --same-device to rehearse "
+                             "%d ranks on one GPU)\n" % (n, have, n))
+            return 2
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
+    import threading
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    rc = 0
+    live = set(range(n))
+    while live and rc == 0:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0:
+                rc = code if code > 0 else 128 - code
+                sys.stderr.write("bench.py: rank %d exited with code %d\n" % (r, code))
+                break
+        time.sleep(0.05)
+    if rc != 0:
+        for r in live:
+            procs[r].terminate()
+        for r in live:
+            try:
+                procs[r].wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+        return rc
+    reader.join(timeout=10)
+    text = (out0[0] if out0 else b"").decode("utf-8", "replace")
+    lines = [ln for ln in text.splitlines() if ln.strip().startswith("{")]
+    if not lines:
+        sys.stderr.write("bench.py: rank 0 printed no result line\n")
+        return 3
+    sys.stdout.write(lines[-1] + "\n")
+    sys.stdout.flush()
+    return 0
+
+
 def emit(result, real_stdout):
     """The one JSON line, on the process's original standard output."""
     sys.stdout.flush()
@@ -290,6 +380,8 @@ def emit(result, real_stdout):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args, sys.argv[1:]))
     if os.environ.get("OFRI_BENCH_WATCHDOG"):       # seconds after which every thread's stack is dumped and the run ends
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["OFRI_BENCH_WATCHDOG"]), exit=True)
@@ -301,7 +393,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     dist = torch = None
     multi = world > 1 or args.force_dist
@@ -309,11 +401,29 @@ def main():
         import torch
         import torch.distributed as dist
         if args.force_dist and "RANK" not in os.environ:        # one rank started by hand: be its own rendezvous
-            for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29511")):
+            for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", str(_free_port()))):
                 os.environ.setdefault(k, v)
+        if args.launch_check:
+            if os.environ.get("OFRI_BENCH_FAIL_RANK") == str(rank):      # test hook: a rank that dies before the rendezvous
+                raise SystemExit(5)
+            dist.init_process_group("gloo")
+            t = torch.tensor([float(rank)])
+            dist.all_reduce(t)
+            if rank == 0:
+                emit({"launch_check": True, "n_gpus": world, "rank_sum": float(t.item()),
+                      "same_device": bool(args.same_device)}, real_stdout)
+            dist.barrier()
+            dist.destroy_process_group()
+            return
+        if not args.same_device and torch.cuda.device_count() <= local:
+            raise SystemExit("bench.py: rank %d needs GPU %d but %d GPU(s) are visible (use --same-device to rehearse on one)"
+                             % (rank, local, torch.cuda.device_count()))
         if args.backend == "nccl":
             torch.cuda.set_device(0 if args.same_device else local)
-        dist.init_process_group(args.backend)
+            # the device is named: the communicator is bound to it at once instead of guessing it from the rank
+            dist.init_process_group(args.backend, device_id=torch.device("cuda", 0 if args.same_device else local))
+        else:
+            dist.init_process_group(args.backend)
 
     if args.batch:
         if not multi:
@@ -468,12 +578,13 @@ def main():
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = world * pairs_per_step * H * W * args.steps / dt / 1e6
-        roof = roofline_block(recs, H, W, rec_steps, ms_per_step)
+        one_sweep = one_sweep_roofline(ctx, H, W) if (world == 1 and args.fuse == 0) else None
+        roof = roofline_block(recs, H, W, rec_steps, ms_per_step, one_sweep)
         if roof is not None and plan is not None:
             roof["timed_in"] = ("the last of the %d replays of the captured graph" % args.steps if timed_graph else
                                 "two kernel-by-kernel steps after the timed replays")
-        if roof is not None and world == 1 and args.fuse == 0:
-            roof["one_sweep_kernel"] = one_sweep_roofline(ctx, H, W)
+        if roof is not None and one_sweep is not None:
+            roof["one_sweep_kernel"] = one_sweep
         result = {
             "metric": "Mpix/s per PIV frame pair (HS 100-iter @4096^2)",
             "value": value, "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -481,7 +592,13 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "HS Fs3.4, 2-level pyramid, %dx%d synthetic Poiseuille pair, alphas [21,45], "
                                    "%d sweeps/level%s" % (H, W, args.niter, " + Liu-Shen h=5 Fs_opt 0.48 on every level" if args.liushen else ""),
-                       "pairs_per_step_per_gpu": pairs_per_step, "flow_gather": gather_note, "captured_graph": plan is not None, "launch_mode_note": graph_note,
+                       "pairs_per_step_per_gpu": pairs_per_step, "flow_gather": gather_note, "captured_graph": plan is not None,
+                       "launch_mode_note": graph_note if not multi else
+                       ((graph_note + "; ") if graph_note else "") +
+                       "ranks under torch.distributed run on the HIP runtime of torch's wheel (a step is about 3 % slower there "
+                       "than on the system's runtime that a single-process run uses, so the N = 1 value of a multi-rank launch is "
+                       "not the single-process value); the timed steps replay an untimed captured graph, and the roofline block "
+                       "comes from two kernel-by-kernel steps after the timed region",
                        "hs_sweeps_per_launch": roof["sweeps_per_launch"] if roof else None},
             "roofline": roof,
         }

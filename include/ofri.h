@@ -54,6 +54,11 @@ int ofri_ctx_stream(ofri_ctx *ctx, void **stream);
 int ofri_alloc(ofri_ctx *ctx, size_t bytes, void **dptr);
 int ofri_free(ofri_ctx *ctx, void *dptr);
 int ofri_pool_trim(ofri_ctx *ctx);
+/* Allocation counters, for callers and tests that must show a code path allocates nothing: *runtime_allocs = allocating
+ * HIP runtime calls this library has made in this process so far (hipMalloc, hipHostMalloc, event creation; all
+ * contexts), *pool_requests = ofri_alloc calls on this context so far (served from the pool or not).  Either pointer may
+ * be null.  No counterpart in the reference (PyOpenCL allocates a cl.Buffer per kernel call, Farneback_PyCL.py:225-229). */
+int ofri_alloc_stats(ofri_ctx *ctx, unsigned long long *runtime_allocs, unsigned long long *pool_requests);
 int ofri_upload(ofri_ctx *ctx, void *dst, const void *src_host, size_t bytes);     /* blocking */
 int ofri_download(ofri_ctx *ctx, void *dst_host, const void *src, size_t bytes);   /* blocking */
 int ofri_copy(ofri_ctx *ctx, void *dst, const void *src, size_t bytes);            /* device->device */

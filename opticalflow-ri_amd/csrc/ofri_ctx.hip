@@ -1,5 +1,6 @@
 // Context, pooled device memory, copies, events, small conversions and reductions.
 #include "ofri_internal.h"
+#include <atomic>
 
 static thread_local char g_err[512] = "";
 
@@ -35,6 +36,10 @@ extern "C" int ofri_device_count(int *count) {
 
 int ofri_hs_static_setup(int device);
 
+// Every allocating runtime call this library makes (device and pinned memory, events) is counted; ofri_alloc_stats reads it.
+std::atomic<unsigned long long> g_ofri_runtime_allocs{0};
+#define OFRI_COUNT_ALLOC() (void)g_ofri_runtime_allocs.fetch_add(1, std::memory_order_relaxed)
+
 extern "C" int ofri_ctx_create(int device, void *stream, ofri_ctx **out) {
     OFRI_REQUIRE(out, "out is null");
     *out = nullptr;
@@ -43,7 +48,9 @@ extern "C" int ofri_ctx_create(int device, void *stream, ofri_ctx **out) {
         return ofri_set_error(OFRI_ENODEVICE, "no HIP device available (libofri_hip needs an AMD GPU; there is no CPU fallback)");
     OFRI_REQUIRE(device >= 0 && device < n, "device %d out of range (0..%d)", device, n - 1);
     OFRI_HIP(hipSetDevice(device));
-    OFRI_TRY(ofri_hs_static_setup(device));       // address of the allocation-free entry point's scratch array on this GPU
+    // Address of the allocation-free entry point's scratch array on this GPU.  A failure here does not stop the context:
+    // ofri_hs_compute_static reports the missing address when it is called, every other entry point works without it.
+    if (ofri_hs_static_setup(device) != OFRI_OK) (void)hipGetLastError();
     ofri_ctx *c = new ofri_ctx();
     c->device = device;
     if (stream) {
@@ -53,6 +60,7 @@ extern "C" int ofri_ctx_create(int device, void *stream, ofri_ctx **out) {
         if (e != hipSuccess) { delete c; return ofri_set_error(OFRI_EHIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
         c->owns_stream = true;
     }
+    OFRI_COUNT_ALLOC();
     hipError_t e = hipHostMalloc(&c->pinned, 4096, hipHostMallocDefault);
     if (e != hipSuccess) { delete c; return ofri_set_error(OFRI_EHIP, "hipHostMalloc: %s", hipGetErrorString(e)); }
     *out = c;
@@ -106,6 +114,7 @@ extern "C" int ofri_alloc(ofri_ctx *ctx, size_t bytes, void **dptr) {
     OFRI_REQUIRE(dptr, "dptr is null");
     *dptr = nullptr;
     OFRI_REQUIRE(bytes > 0, "zero-byte allocation");
+    ctx->pool_requests += 1;
     size_t rb = round_block(bytes);
     void *p = nullptr;
     if (ctx->capturing) {
@@ -123,6 +132,7 @@ extern "C" int ofri_alloc(ofri_ctx *ctx, size_t bytes, void **dptr) {
         p = it->second.back();
         it->second.pop_back();
     } else {
+        OFRI_COUNT_ALLOC();
         hipError_t e = hipMalloc(&p, rb);
         if (e != hipSuccess) {
             // release cached blocks and retry once
@@ -134,6 +144,13 @@ extern "C" int ofri_alloc(ofri_ctx *ctx, size_t bytes, void **dptr) {
     ctx->live[p] = rb;
     if (ctx->capturing) ctx->cap_blocks[p] = rb;
     *dptr = p;
+    return OFRI_OK;
+}
+
+extern "C" int ofri_alloc_stats(ofri_ctx *ctx, unsigned long long *runtime_allocs, unsigned long long *pool_requests) {
+    OFRI_REQUIRE(ctx, "null context");
+    if (runtime_allocs) *runtime_allocs = g_ofri_runtime_allocs.load(std::memory_order_relaxed);
+    if (pool_requests) *pool_requests = ctx->pool_requests;
     return OFRI_OK;
 }
 
@@ -286,6 +303,7 @@ int ofri_cached_table(ofri_ctx *ctx, const std::string &key, const void *host, s
     void *p = ofri_find_table(ctx, key);
     if (!p) {
         OFRI_REQUIRE(!ctx->capturing, "a constant table is missing: run the sequence once before capturing it");
+        OFRI_COUNT_ALLOC();
         OFRI_HIP(hipMalloc(&p, bytes));
         hipError_t e = hipMemcpy(p, host, bytes, hipMemcpyHostToDevice);
         if (e != hipSuccess) { (void)hipFree(p); return ofri_set_error(OFRI_EHIP, "table upload: %s", hipGetErrorString(e)); }
@@ -301,6 +319,7 @@ extern "C" int ofri_event_create(ofri_ctx *ctx, ofri_event **ev) {
     OFRI_REQUIRE(ev, "ev is null");
     ofri_event *e = new ofri_event();
     e->device = ctx->device;
+    OFRI_COUNT_ALLOC();
     hipError_t r = hipEventCreate(&e->ev);
     if (r != hipSuccess) { delete e; return ofri_set_error(OFRI_EHIP, "hipEventCreate: %s", hipGetErrorString(r)); }
     *ev = e;
@@ -478,6 +497,7 @@ __global__ void k_max_final(const double *__restrict__ part, int n, double *__re
 
 static int ensure_red(ofri_ctx *ctx) {
     if (!ctx->red_partials) {
+        OFRI_COUNT_ALLOC();
         OFRI_HIP(hipMalloc((void **)&ctx->red_partials, (RED_BLOCKS + 64) * sizeof(double)));
         ctx->red_capacity = RED_BLOCKS + 64;
     }
@@ -554,6 +574,7 @@ extern "C" int ofri_range_rule_16bit(ofri_ctx *ctx, float *frame0, float *frame1
 // pinned host staging and stream-ordered uploads, for overlapping the next pair's H2D copy with compute
 extern "C" int ofri_host_alloc(size_t bytes, void **hptr) {
     OFRI_REQUIRE(hptr && bytes > 0, "bad argument");
+    OFRI_COUNT_ALLOC();
     OFRI_HIP(hipHostMalloc(hptr, bytes, hipHostMallocDefault));
     return OFRI_OK;
 }
@@ -580,6 +601,7 @@ extern "C" int ofri_ctx_wait(ofri_ctx *ctx, ofri_ctx *other) {
     OFRI_TRY(ofri_check_ctx(ctx));
     OFRI_REQUIRE(other && other->device == ctx->device, "contexts must share a device");
     hipEvent_t ev;
+    OFRI_COUNT_ALLOC();
     OFRI_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     OFRI_HIP(hipEventRecord(ev, other->stream));
     OFRI_HIP(hipStreamWaitEvent(ctx->stream, ev, 0));

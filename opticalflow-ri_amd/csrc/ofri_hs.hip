@@ -1,6 +1,8 @@
 // Horn-Schunck: derivative cube, Jacobi sweeps, error norm.
 // Reference behaviour: src/HornSchunck.py:52-127 (HS_helper2, HS_helper, HS, computeDerivatives).
 #include "ofri_internal.h"
+#include <atomic>
+extern std::atomic<unsigned long long> g_ofri_runtime_allocs;      // ofri_ctx.hip: allocating runtime calls made so far
 #include "ofri_hs_math.h"
 #include "ofri_hs_stream.h"
 
@@ -187,6 +189,7 @@ extern "C" int ofri_hs_set_fuse(ofri_ctx *ctx, int sweeps_per_launch) {
 // at every replay) and the section belongs to the graph (ofri_graph_prof_read).
 static int prof_begin(ofri_ctx *ctx, ofri_ctx::ProfRec &rec) {
     if (!ctx->prof) return OFRI_OK;
+    g_ofri_runtime_allocs.fetch_add(2, std::memory_order_relaxed);
     OFRI_HIP(hipEventCreate(&rec.a)); OFRI_HIP(hipEventCreate(&rec.b));
     if (ctx->capturing) OFRI_HIP(hipEventRecordWithFlags(rec.a, ctx->stream, hipEventRecordExternal));
     else OFRI_HIP(hipEventRecord(rec.a, ctx->stream));
@@ -454,6 +457,7 @@ static __device__ __align__(256) unsigned char scratch[HS_STATIC_BYTES];
 
 #define HS_STATIC_MAX_DEVICES 64
 static void *g_static_ptr[HS_STATIC_MAX_DEVICES];
+static std::atomic<int> g_static_busy[HS_STATIC_MAX_DEVICES];      // a host thread is inside the entry point on that GPU
 static std::mutex g_static_mu;
 
 // Once per device, with that device current (ofri_ctx_create calls this before it makes the context).
@@ -484,12 +488,20 @@ extern "C" int ofri_hs_compute_static(ofri_ctx *ctx, const float *frame0, const 
         std::lock_guard<std::mutex> lock(g_static_mu);
         base = static_cast<unsigned char *>(ctx->device < HS_STATIC_MAX_DEVICES ? g_static_ptr[ctx->device] : nullptr);
     }
-    OFRI_REQUIRE(base, "no scratch address for device %d", ctx->device);
+    OFRI_REQUIRE(base, "no scratch address for device %d (hipGetSymbolAddress failed when the context was made, or the "
+                 "device index is beyond the %d this library tracks)", ctx->device, HS_STATIC_MAX_DEVICES);
+    // Two host threads inside this entry point on one GPU would enqueue onto the same scratch planes: the second is
+    // refused.  (Calls that have returned but whose kernels still run on another stream are not seen here; ordering
+    // those is the caller's, as the header says.)
+    int idle = 0;
+    OFRI_REQUIRE(g_static_busy[ctx->device].compare_exchange_strong(idle, 1),
+                 "ofri_hs_compute_static: another call is in progress on device %d (all calls on a GPU share one scratch array)", ctx->device);
     const bool prof = ctx->prof;            // the timing records create events: not in a call that allocates nothing
     ctx->prof = false;
     const int rc = hs_compute_impl(ctx, frame0, frame1, U_in, V_in, U_out, V_out, alpha, niter, rows, cols, err_host,
                                    reinterpret_cast<float *>(base + HS_STATIC_RED_BYTES), reinterpret_cast<double *>(base));
     ctx->prof = prof;
+    g_static_busy[ctx->device].store(0);
     return rc;
 }
 

@@ -22,6 +22,7 @@ struct ofri_ctx {
     int ncu = 0;                                       // compute units of the device (0 = not queried yet)
     std::map<size_t, std::vector<void *>> pool;        // free blocks by rounded size
     std::map<void *, size_t> live;                     // blocks handed out -> rounded size
+    unsigned long long pool_requests = 0;              // ofri_alloc calls so far (ofri_alloc_stats)
     double *red_partials = nullptr;                    // device scratch for two-stage reductions
     size_t red_capacity = 0;
     std::map<std::string, void *> tables;              // cached device-resident constant tables

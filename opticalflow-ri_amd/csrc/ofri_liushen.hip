@@ -252,11 +252,15 @@ __device__ __forceinline__ double ls_total_error(double ta, double tb, double in
 
 // Counts the T (at most 8) sweeps of the block before this launch's from their per-workgroup partial sums,
 // partials[(2 * j + {0, 1}) * nparts + w]; src / dst: the buffers that block read / wrote.  One workgroup (a multiple of
-// 64 and at most 256 threads) inside launch k; its wavefronts sum different sweeps side by side.
+// 64 and at most 64 * LS_CHECK_WAVES threads: the pipelines run it with five wavefronts, the one-sweep kernel with four)
+// inside launch k; its wavefronts sum different sweeps side by side.
 struct LsPrev { const double *partials; int nparts, T, src, dst; };
+#define LS_CHECK_WAVES 8
 __device__ void ls_check(const LsPrev &pv, double inv_rc, double tol, LsState *state, int k) {
-    __shared__ double sums[8][4][2];        // [sweep][slice][u | v]
-    const int tid = threadIdx.y * blockDim.x + threadIdx.x, nthr = blockDim.x * blockDim.y, nw = nthr >> 6, w = tid >> 6, ln = tid & 63;
+    __shared__ double sums[8][LS_CHECK_WAVES][2];        // [sweep][slice][u | v]; a slice index never reaches nw
+    const int tid = threadIdx.y * blockDim.x + threadIdx.x, nthr = blockDim.x * blockDim.y, w = tid >> 6, ln = tid & 63;
+    const int nw = min(nthr >> 6, LS_CHECK_WAVES);
+    if (w >= nw) return;                       // before the barrier below, which only the counted wavefronts reach
     if (state->done[(k + 1) & 1]) {            // met before: hand the flag on
         if (tid == 0) state->done[k & 1] = 1;
         return;
@@ -572,6 +576,7 @@ __global__ void __launch_bounds__((LtCfg<NL, PX>::THREADS), (LtCfg<NL, PX>::PER_
 k_ls_stream(LsBufs bufs, int src, int dst, const float *__restrict__ coefs, long long plane, float h, int H, int W, int T, int tiles_x,
             int chunk_rows, LsState *state, double *__restrict__ partials, LsPrev pv, int k, double inv_rc, double tol, OfriPrio pr) {
     constexpr int NS = LtCfg<NL, PX>::NS, CR = LtCfg<NL, PX>::CR, LAG = LtCfg<NL, PX>::LAG, ST = LtCfg<NL, PX>::STAGE_THREADS, LN = LtCfg<NL, PX>::LN;
+    static_assert(LtCfg<NL, PX>::THREADS / 64 <= LS_CHECK_WAVES, "ls_check sizes its LDS for at most LS_CHECK_WAVES wavefronts");
     if (REDO) {
         if (blockIdx.x == 0) return;
         T = state->redo;

@@ -447,7 +447,7 @@ extern "C" int ofri_lk_compute(ofri_ctx *ctx, const float *im1, const float *im2
         k_lk_tile<<<tiles, 256, 0, ctx->stream>>>(im1, im2, U_in, V_in, U_out, V_out, rows, cols, niter, tiles_x, list, count);
         OFRI_LAUNCH_CHECK();
         int gl = (int)((n + LK_PX - 1) / LK_PX);
-        if (gl > 2048) gl = 2048;
+        if (gl > 512) gl = 512;              // a small resident grid: the kernel loops over *count, which is mostly zero
         k_lk_list<<<gl, 64 * LK_PX, 0, ctx->stream>>>(im1, im2, U_in, V_in, U_out, V_out, rows, cols, p, list, count);
         OFRI_LAUNCH_CHECK();
         return OFRI_OK;

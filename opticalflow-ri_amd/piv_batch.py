@@ -97,7 +97,8 @@ def _one_hip_runtime():
 def torch_context(device=0, make_current=True):
     """An _ofri.Context whose stream is a torch stream (made current unless ``make_current`` is false): the library's
     kernels, torch's copies and the RCCL collectives torch enqueues are then ordered against each other.  Returns
-    (ctx, torch_stream); the context remembers the stream as ``ctx.torch_stream``."""
+    (ctx, torch_stream); the context remembers the stream as ``ctx.torch_stream``, and run_batch orders its copies and
+    collectives against that recorded stream, never against whatever stream happens to be current."""
     import torch
     import _ofri
     _one_hip_runtime()
@@ -114,10 +115,11 @@ def flow_lanes(n, make_flow, device=0):
     """``n`` independent (ctx, flow_fn) lanes on one GPU for run_batch(lanes=...): each its own stream, pool and captured
     graph, so that n pairs are in flight at once (the launches of one pair leave gaps and tails that another pair's fill;
     2048 x 2048 Horn-Schunck + Liu-Shen: 3 lanes give 1.4 times the pairs per second of one).  ``make_flow(ctx)``
-    returns the lane's flow function (e.g. lambda c: hs_liushen_flow(c, shape)).  The first lane's stream is current."""
+    returns the lane's flow function (e.g. lambda c: hs_liushen_flow(c, shape)).  The caller's current torch stream is
+    left as it is."""
     out = []
     for i in range(max(1, int(n))):
-        ctx, _ = torch_context(device, make_current=(i == 0))
+        ctx, _ = torch_context(device, make_current=False)
         # half as many row chunks per launch once another lane fills the rest of the GPU (64 pairs of 2048 x 2048 on three
         # lanes: 2670 -> 2955 Mpix/s; a third of the chunks 2890, a quarter 2670).  Before make_flow: a captured graph
         # keeps the launch shapes of its capture
@@ -188,8 +190,11 @@ def run_batch(n_pairs, pair_fn, flow_fn, ctx=None, group=None, dst=0, chunk=8, g
 
     Returns on rank ``dst`` a float32 tensor (n_pairs, 2, H, W) in pair order ([p, 0] = U, [p, 1] = V), None on the
     other ranks; with ``gather=False`` every rank returns its own block (n_local, 2, H, W).  Without an initialised
-    process group the call is the single-rank case.  ``ctx`` must have been made by torch_context() when tensors
-    live on the GPU, so that copies, kernels and collectives share a stream order.  ``shape``: (H, W) of a field;
+    process group the call is the single-rank case.  ``ctx`` must have been made by torch_context() when fields are
+    gathered on the GPU or further lanes are given: the gather stream and the lanes are ordered against the streams the
+    contexts recorded (``ctx.torch_stream``), whatever torch's current stream is.  DeviceArrays that ``pair_fn`` hands
+    out must be complete on ctx's stream when run_batch is called (frames resident before the call: every lane waits
+    for ctx's stream once, at the start) or be produced on the context of the lane that will use them.  ``shape``: (H, W) of a field;
     needed only when a rank may have no pairs (more ranks than pairs), otherwise taken from the first result.
     ``stats``: optional dict that receives 'elapsed_s' (this rank's time from its first pair to its last gather) and
     'pairs' (the rank's count).  ``lanes``: further (ctx, flow_fn) pairs on the same GPU (flow_lanes); the rank's k-th
@@ -207,6 +212,8 @@ def run_batch(n_pairs, pair_fn, flow_fn, ctx=None, group=None, dst=0, chunk=8, g
     lane_streams = [getattr(c, "torch_stream", None) for c, _ in L]
     if len(L) > 1 and any(st is None for st in lane_streams):
         raise ValueError("lanes need contexts made by torch_context() / flow_lanes()")
+    for st in lane_streams[1:]:
+        st.wait_stream(lane_streams[0])         # frames made resident through ctx before this call
     if n_pairs < 0 or not callable(pair_fn) or not callable(flow_fn):
         raise ValueError("run_batch(n_pairs >= 0, pair_fn(p), flow_fn(im0, im1))")
     parts = partition(n_pairs, job.world)
@@ -237,6 +244,9 @@ def run_batch(n_pairs, pair_fn, flow_fn, ctx=None, group=None, dst=0, chunk=8, g
             if job.rank == dst:     # rank r's chunk c lands in result[r, c*chunk:(c+1)*chunk]: a contiguous view each
                 state["result"] = torch.empty((job.world, n_chunks * chunk, 2, H, W), dtype=torch.float32, device=job.device)
             if on_gpu and not host_exchange:
+                if lane_streams[0] is None:
+                    raise ValueError("run_batch: gathering GPU tensors needs a context made by torch_context() "
+                                     "(its stream orders the send buffer's copies before the collective)")
                 state["comm"] = torch.cuda.Stream(device=job.device)
         else:
             state["local"] = torch.empty((n_local, 2, H, W), dtype=torch.float32, device=job.device)
@@ -259,8 +269,7 @@ def run_batch(n_pairs, pair_fn, flow_fn, ctx=None, group=None, dst=0, chunk=8, g
         recv = [state["result"][r, c * chunk:(c + 1) * chunk] for r in range(job.world)] if job.rank == dst else None
         comm = state["comm"]
         if comm is not None:
-            comm.wait_stream(torch.cuda.current_stream())        # the chunk's fields are complete
-            for st in lane_streams[1:]:
+            for st in lane_streams:                              # the chunk's fields are complete on every lane
                 comm.wait_stream(st)
             with torch.cuda.stream(comm):
                 w = job.dist.gather(buf, recv, dst=dst, group=job.group, async_op=True)
@@ -272,11 +281,12 @@ def run_batch(n_pairs, pair_fn, flow_fn, ctx=None, group=None, dst=0, chunk=8, g
         """Before chunk c's send buffer is written again, the gather that last read it (chunk c - 2) must be over."""
         while len(pending) >= 2:
             w = pending.pop(0)
-            w.wait()                                             # orders the current stream (lane 0) after the gather
             if state["comm"] is not None:
-                for st in lane_streams[1:]:                      # and every other lane's
+                for st in lane_streams:                          # every lane's stream is ordered after the gather
                     with torch.cuda.stream(st):
                         w.wait()
+            else:
+                w.wait()
 
     if shape is not None:
         setup(shape)
@@ -301,10 +311,15 @@ def run_batch(n_pairs, pair_fn, flow_fn, ctx=None, group=None, dst=0, chunk=8, g
         if do_gather:
             post(c)
     while pending:
-        pending.pop(0).wait()
+        w = pending.pop(0)
+        if state["comm"] is not None:
+            with torch.cuda.stream(lane_streams[0]):
+                w.wait()
+        else:
+            w.wait()
     if on_gpu:
         if state["comm"] is not None:
-            torch.cuda.current_stream().wait_stream(state["comm"])
+            lane_streams[0].wait_stream(state["comm"])
         for lctx, _ in L:
             lctx.sync()
     if stats is not None:

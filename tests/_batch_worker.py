@@ -36,7 +36,7 @@ def no_group():
         np.testing.assert_array_equal(got[p, 1], V.numpy())
     # three pairs in flight: lane k takes the rank's pairs k, k + 3, ...; same fields in the same order
     lanes = piv_batch.flow_lanes(2, lambda c: piv_batch.hs_liushen_flow(c, (H, W), niter=16, liushen=False, graph=True), 0)
-    torch.cuda.set_stream(stream)
+    torch.cuda.set_stream(torch.cuda.default_stream())      # the runner orders against the contexts' own streams
     out3 = piv_batch.run_batch(3, lambda p: resident[p], flow, ctx=ctx, chunk=2, lanes=lanes)
     np.testing.assert_array_equal(out3.cpu().numpy(), got)
     for _, f in lanes:
@@ -45,9 +45,57 @@ def no_group():
     print("BATCH-OK")
 
 
+def cfg5_share(port):
+    """One GPU's share of the 512-pair configuration at its own size and shape: 64 pairs of 2048 x 2048, Horn-Schunck +
+    Liu-Shen per pair from captured graphs on three lanes, frames resident as uint8, one RCCL gather per chunk of 8
+    (process group of one rank).  Every ninth field (pairs 0, 9, ... 63: every lane, every slot of a chunk, both send
+    buffers) is compared bit for bit with the driver called on that pair alone."""
+    import time
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    import piv_batch
+    from piv_synth import synth_piv
+    from HornSchunck import HSOpticalFlowAlgoAdapter
+    from PhysicsBasedOpticalFlowLiuShen import LiuShenOpticalFlowAlgoAdapter
+    from GenericPyramidalOpticalFlow import pyramidal_flow_device
+    H = W = 2048
+    n_pairs, distinct = 64, 8
+    lanes = piv_batch.flow_lanes(3, lambda c: piv_batch.hs_liushen_flow(c, (H, W), graph=True), 0)
+    (ctx, flow), more = lanes[0], lanes[1:]
+    host = [synth_piv(H, W, seed=k) for k in range(distinct)]
+    print("frames rendered", flush=True)
+    resident = [(ctx.upload(a, np.uint8), ctx.upload(b, np.uint8)) for a, b in host]
+    t = time.perf_counter()
+    out = piv_batch.run_batch(n_pairs, lambda p: resident[p % distinct], flow, ctx=ctx, chunk=8, shape=(H, W), lanes=more)
+    print("batch of %d pairs: %.1f ms per pair" % (n_pairs, (time.perf_counter() - t) * 1e3 / n_pairs), flush=True)
+    assert tuple(out.shape) == (n_pairs, 2, H, W) and out.is_cuda
+    assert bool(torch.isfinite(out).all())
+    for p in range(0, n_pairs, 9):
+        a, b = host[p % distinct]
+        U, V = pyramidal_flow_device(ctx.upload(a.astype(np.float32)), ctx.upload(b.astype(np.float32)), 3.4,
+                                     HSOpticalFlowAlgoAdapter([21, 45], 100), 2, 1, 0.48, LiuShenOpticalFlowAlgoAdapter(5))
+        got = out[p].cpu().numpy()
+        np.testing.assert_array_equal(got[0], U.numpy(), err_msg="pair %d U" % p)
+        np.testing.assert_array_equal(got[1], V.numpy(), err_msg="pair %d V" % p)
+        assert -4.5 < float(got[0][H // 2].mean()) < -3.3            # the Poiseuille pair's centre row
+    # pairs that share a frame pair share a field, whichever lane and chunk slot computed them
+    assert bool(torch.equal(out[3], out[3 + distinct])) and bool(torch.equal(out[5], out[5 + 7 * distinct]))
+    for _, f in lanes:
+        f.close()
+    dist.barrier()
+    dist.destroy_process_group()
+    print("BATCH-OK")
+
+
 def main():
     if sys.argv[1] == "nogroup":
         return no_group()
+    if sys.argv[1] == "cfg5":
+        return cfg5_share(sys.argv[2] if len(sys.argv) > 2 else "29534")
     backend, n_pairs, chunk = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
     import torch
     import torch.distributed as dist
@@ -55,7 +103,9 @@ def main():
     os.environ.setdefault("MASTER_PORT", sys.argv[4] if len(sys.argv) > 4 else "29533")
     if backend == "nccl":
         torch.cuda.set_device(0)
-    dist.init_process_group(backend, rank=0, world_size=1)       # before anything else touches the GPU
+    # before anything else touches the GPU; the device is named, so the communicator is not left guessing it from the rank
+    dist.init_process_group(backend, rank=0, world_size=1,
+                            **({"device_id": torch.device("cuda", 0)} if backend == "nccl" else {}))
     import _ofri
     import piv_batch
     from piv_synth import synth_piv
@@ -85,7 +135,9 @@ def main():
         np.testing.assert_array_equal(loc.cpu().numpy(), got)
         # several pairs in flight (each lane its own stream and graph), gathered chunk by chunk as before
         lanes = piv_batch.flow_lanes(2, lambda c: piv_batch.hs_liushen_flow(c, (H, W), niter=niter, graph=graph), 0)
-        torch.cuda.set_stream(stream)
+        # torch's current stream is none of the lanes' from here on: the runner must order the gather against the
+        # streams the contexts recorded, not against the ambient one
+        torch.cuda.set_stream(torch.cuda.default_stream())
         out3 = piv_batch.run_batch(n_pairs, lambda p: frames[p], flow, ctx=ctx, chunk=chunk, lanes=lanes)
         np.testing.assert_array_equal(out3.cpu().numpy(), got, err_msg="lanes (graph=%s)" % graph)
         for _, f in lanes:

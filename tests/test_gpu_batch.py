@@ -2,6 +2,7 @@
 runs - resident frames widened on the GPU, per-pair flow, per-chunk asynchronous gather over RCCL into the result
 tensor - and every gathered field must equal the driver's, pair by pair, bit for bit."""
 import os
+import socket
 import subprocess
 import sys
 
@@ -14,13 +15,28 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 @pytest.mark.parametrize("n_pairs,chunk", [(5, 2), (4, 4)])
 def test_run_batch_over_rccl_world_size_1(n_pairs, chunk):
     """In a child process, so that the process group is initialised before anything else touches the GPU."""
-    _child("nccl", n_pairs, chunk, port=29540 + n_pairs)
+    _child("nccl", n_pairs, chunk)
 
 
-def _child(*argv, port=29539):
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_one_gpus_share_of_the_512_pair_configuration():
+    """64 pairs of 2048 x 2048 on three lanes with the RCCL gather per chunk of 8: the runner at the configuration's own
+    size and shape (examples/LiuSE_PyHSchunck_Fs3_4_PyrLvls2.py:133-139 per pair)."""
+    _child("cfg5", str(_free_port()), timeout=280)
+
+
+def _child(*argv, timeout=110):
+    port = _free_port()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     r = subprocess.run([sys.executable, "-u", os.path.join(HERE, "_batch_worker.py")] + [str(a) for a in argv],
-                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=110)
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout)
     text = r.stdout.decode("utf-8", "replace")
     assert r.returncode == 0 and "BATCH-OK" in text, text[-3000:]
 

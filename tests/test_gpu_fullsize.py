@@ -92,6 +92,19 @@ def test_headline_configuration_4096_vs_oracle(ctx, oracle):
     _ofri.check(lib.ofri_u8_to_f32(ctx.handle, u1.ptr, im1.ptr, n * n))
     Ua, Va = pyramidal_flow_device(im0, im1, 3.4, HSOpticalFlowAlgoAdapter([21, 45], 100), 2, 1, None)
     U, V = Ua.numpy(), Va.numpy()
+    # the object bench.py times: the same pair replayed from the captured graph of piv_plan.FlowPlan (at this size with the
+    # 256-column strips), twice, must give the kernel-by-kernel result bit for bit
+    from piv_plan import FlowPlan
+    plan = FlowPlan((n, n), 3.4, lambda: HSOpticalFlowAlgoAdapter([21, 45], 100), pyramidalLevels=2, ctx=ctx, timed=True)
+    try:
+        plan.load(im0, im1)
+        for _ in range(2):
+            Ug, Vg = plan.run()
+            np.testing.assert_array_equal(Ug.numpy(), U)
+            np.testing.assert_array_equal(Vg.numpy(), V)
+        assert len(plan.prof_records()) > 0
+    finally:
+        plan.close()
     Ur, Vr = oracle(("hs2", 4096, 0))
     _check("HS 2-level 4096^2 (headline)", U, V, Ur, Vr)
     # the Poiseuille profile the frames were rendered with: -4 px at the centre row, 0 at the walls
@@ -103,6 +116,27 @@ def test_farneback_two_level_1024_vs_oracle(ctx, oracle):
     from Farneback_PyCL import Farneback_PyCL
     U, V = _flow(ctx, 1024, 0, 0.0, Farneback_PyCL(), 2, 1, None)
     _check("Farneback 2-level 1024^2", U, V, *oracle(("fb2", 1024, 0)))
+
+
+def test_farneback_two_level_4096_fast_vs_exact_and_profile(ctx):
+    """The Farneback configuration at its own size (4096 x 4096, 2 levels; examples/Farneback_Fs0_0_PyrLvls2.py:73).  The NumPy
+    oracle would need many minutes there, so the check is size-independent: the default fast mode (fused multiply-adds)
+    against the exact mode (separately rounded, bit-identical to the oracle at the sizes the oracle is run on) below
+    1e-5, and the Poiseuille profile the frames were rendered with."""
+    from Farneback_PyCL import Farneback_PyCL
+    n = 4096
+    U, V = _flow(ctx, n, 0, 0.0, Farneback_PyCL(), 2, 1, None)
+    ctx.set_fb_mode(-1)
+    try:
+        Ue, Ve = _flow(ctx, n, 0, 0.0, Farneback_PyCL(), 2, 1, None)
+    finally:
+        ctx.set_fb_mode(0)
+    r = _check("Farneback 2-level 4096^2 fast vs exact mode", U, V, Ue, Ve, tol=1e-5)
+    assert r > 0                                          # two different arithmetic paths did run
+    prof = Ue.mean(axis=1)
+    assert -4.3 < prof[n // 2] < -3.5 and abs(prof[8]) < 0.8 and float(np.abs(Ve).mean()) < 0.1
+    q = n // 4                                            # parabola: three quarters of the centre value at the quarter rows
+    assert abs(prof[q] / prof[n // 2] - 0.75) < 0.06 and abs(prof[3 * q] / prof[n // 2] - 0.75) < 0.06
 
 
 def test_farneback_plus_liushen_2048_vs_oracle(ctx, oracle):

@@ -609,7 +609,7 @@ def test_liushen_launch_shapes_agree_bitwise(ctx, shape):
     U0 = (0.3 * rng.standard_normal(shape)).astype(np.float32); V0 = (0.3 * rng.standard_normal(shape)).astype(np.float32)
     d = [ctx.upload(x) for x in (I0, I1, U0, V0)]
     try:
-        for maxit in (1, 5, 6, 7, 13, 60):
+        for maxit in (1, 5, 6, 7, 9, 13, 17, 60):
             res = {}
             for mode in (1, 6, 8, -1):
                 ctx.set_ls_mode(mode)

@@ -22,6 +22,39 @@ def ctx():
     return _ofri.context()
 
 
+def _alloc_counts(ctx):
+    """(allocating HIP runtime calls the library has made so far, ofri_alloc requests on this context so far)"""
+    import _ofri
+    a, b = C.c_ulonglong(0), C.c_ulonglong(0)
+    _ofri.check(_ofri.lib().ofri_alloc_stats(ctx.handle, C.byref(a), C.byref(b)))
+    return a.value, b.value
+
+
+def test_static_entry_allocates_nothing(ctx):
+    """The library counts its allocating runtime calls (hipMalloc, hipHostMalloc, event creation) and the requests to a
+    context's pool: neither moves across static calls, both move across the pooled entry point."""
+    import _ofri
+    lib = _ofri.lib()
+    static = _ofri.bind("ofri_hs_compute_static", ARGS)
+    for shape, niter, prof in (((384, 512), 30, False), ((130, 203), 7, False), ((256, 256), 12, True)):
+        a, b = _frames(shape, seed=3)
+        rows, cols = shape
+        da, db, Uo, Vo = ctx.upload(a), ctx.upload(b), ctx.empty(shape), ctx.empty(shape)
+        err = C.c_double(-1.0)
+        ctx.prof_enable(prof)                   # the timing records would create events: the static call skips them
+        try:
+            before = _alloc_counts(ctx)
+            for _ in range(2):
+                _ofri.check(static(ctx.handle, da.ptr, db.ptr, None, None, Uo.ptr, Vo.ptr, 21.0, niter, rows, cols, C.byref(err)))
+            ctx.sync()
+            assert _alloc_counts(ctx) == before, (shape, before, _alloc_counts(ctx))
+            _ofri.check(lib.ofri_hs_compute(ctx.handle, da.ptr, db.ptr, None, None, Uo.ptr, Vo.ptr, 21.0, niter, rows, cols, C.byref(err)))
+            after = _alloc_counts(ctx)
+            assert after[1] > before[1]         # the pooled entry point does ask the pool: the counter is alive
+        finally:
+            ctx.prof_enable(False)
+
+
 def _both(ctx, a, b, U0, V0, alpha, niter):
     """(U, V, err) from ofri_hs_compute and from ofri_hs_compute_static on the same device inputs."""
     import _ofri
