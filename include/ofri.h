@@ -59,6 +59,13 @@ int ofri_pool_trim(ofri_ctx *ctx);
  * contexts), *pool_requests = ofri_alloc calls on this context so far (served from the pool or not).  Either pointer may
  * be null.  No counterpart in the reference (PyOpenCL allocates a cl.Buffer per kernel call, Farneback_PyCL.py:225-229). */
 int ofri_alloc_stats(ofri_ctx *ctx, unsigned long long *runtime_allocs, unsigned long long *pool_requests);
+/* Debugging aid, no counterpart in the reference.  With OFRI_POOL_GUARD=<KiB> in the environment when the library is
+ * loaded, every pool block carries that many KiB of 0xC3 bytes (0xFF with OFRI_POOL_GUARD_NAN=1: float NaNs, so that
+ * reads outside an array reach the results) before and after it; this call waits for the device and counts the blocks,
+ * of all contexts, whose bands were written to (*bad_blocks; the first one's size and the offending byte's offset from
+ * the block's start in the optional outputs).  OFRI_EINVAL when the bands are off.  OFRI_POOL_POISON=1 fills every block
+ * with 0xFF bytes when it is handed out, so that a kernel reading memory nobody wrote in that call shows up as NaNs. */
+int ofri_pool_guard_check(ofri_ctx *ctx, int *bad_blocks, unsigned long long *first_bad_size, long long *first_bad_offset);
 int ofri_upload(ofri_ctx *ctx, void *dst, const void *src_host, size_t bytes);     /* blocking */
 int ofri_download(ofri_ctx *ctx, void *dst_host, const void *src, size_t bytes);   /* blocking */
 int ofri_copy(ofri_ctx *ctx, void *dst, const void *src, size_t bytes);            /* device->device */

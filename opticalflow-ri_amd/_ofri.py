@@ -34,6 +34,7 @@ _PROTOS = {
     "ofri_free": ([_vp, _vp], _i),
     "ofri_pool_trim": ([_vp], _i),
     "ofri_alloc_stats": ([_vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)], _i),
+    "ofri_pool_guard_check": ([_vp, C.POINTER(_i), C.POINTER(C.c_ulonglong), C.POINTER(C.c_longlong)], _i),
     "ofri_upload": ([_vp, _vp, _vp, _sz], _i),
     "ofri_download": ([_vp, _vp, _vp, _sz], _i),
     "ofri_copy": ([_vp, _vp, _vp, _sz], _i),

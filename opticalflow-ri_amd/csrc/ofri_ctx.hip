@@ -1,6 +1,7 @@
 // Context, pooled device memory, copies, events, small conversions and reductions.
 #include "ofri_internal.h"
 #include <atomic>
+#include <mutex>
 
 static thread_local char g_err[512] = "";
 
@@ -67,11 +68,86 @@ extern "C" int ofri_ctx_create(int device, void *stream, ofri_ctx **out) {
     return OFRI_OK;
 }
 
+// ---- guard bands (debugging aid): with OFRI_POOL_GUARD=<KiB> in the environment every pool block is allocated with that many
+// KiB of 0xC3 bytes before and after it, and ofri_pool_guard_check reports blocks whose bands were written to (a kernel that
+// stores outside its arrays).  Off by default: nothing below changes the normal path.
+static size_t guard_bytes() {
+    static const size_t g = [] {
+        const char *e = getenv("OFRI_POOL_GUARD");
+        return e ? (size_t)strtoul(e, nullptr, 10) * 1024 : (size_t)0;
+    }();
+    return g;
+}
+static int guard_fill() {            // OFRI_POOL_GUARD_NAN=1: bands of 0xFF bytes (float NaNs), so that reads outside an array reach the results
+    static const int v = getenv("OFRI_POOL_GUARD_NAN") ? 0xFF : 0xC3;
+    return v;
+}
+static std::map<void *, size_t> g_guarded;          // every guarded block of the process (user pointer -> size)
+static std::mutex g_guarded_mu;
+// OFRI_POOL_POISON=1 (debugging aid): every block handed out is first filled with 0xFF bytes (float NaNs) in the order of the
+// context's stream, so that a kernel reading memory nobody wrote in this call shows up as NaNs in the results.
+static bool pool_poison() {
+    static const bool on = getenv("OFRI_POOL_POISON") != nullptr;
+    return on;
+}
+static hipError_t pool_malloc(void **p, size_t rb) {
+    const size_t G = guard_bytes();
+    if (!G) return hipMalloc(p, rb);
+    char *base = nullptr;
+    hipError_t e = hipMalloc((void **)&base, rb + 2 * G);
+    if (e != hipSuccess) return e;
+    (void)hipMemset(base, guard_fill(), G);
+    (void)hipMemset(base + G + rb, guard_fill(), G);
+    *p = base + G;
+    std::lock_guard<std::mutex> lock(g_guarded_mu);
+    g_guarded[*p] = rb;
+    return hipSuccess;
+}
+static void pool_free(void *p) {
+    if (guard_bytes()) {
+        std::lock_guard<std::mutex> lock(g_guarded_mu);
+        g_guarded.erase(p);
+    }
+    (void)hipFree(guard_bytes() ? (void *)((char *)p - guard_bytes()) : p);
+}
+
+extern "C" int ofri_pool_guard_check(ofri_ctx *ctx, int *bad_blocks, unsigned long long *first_bad_size, long long *first_bad_offset) {
+    OFRI_TRY(ofri_check_ctx(ctx));
+    OFRI_REQUIRE(bad_blocks, "null argument");
+    *bad_blocks = 0;
+    const size_t G = guard_bytes();
+    OFRI_REQUIRE(G, "guard bands are off (set OFRI_POOL_GUARD=<KiB> before the library is loaded)");
+    OFRI_HIP(hipDeviceSynchronize());
+    std::vector<unsigned char> h(G);
+    std::vector<std::pair<void *, size_t>> blocks;         // of every context: a stray store may come from any of them
+    {
+        std::lock_guard<std::mutex> lock(g_guarded_mu);
+        for (auto &kv : g_guarded) blocks.push_back({kv.first, kv.second});
+    }
+    for (auto &b : blocks)
+        for (int side = 0; side < 2; ++side) {
+            const char *src = side ? (const char *)b.first + b.second : (const char *)b.first - G;
+            OFRI_HIP(hipMemcpy(h.data(), src, G, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < G; ++i)
+                if (h[i] != guard_fill()) {
+                    if (!*bad_blocks) {
+                        if (first_bad_size) *first_bad_size = b.second;
+                        if (first_bad_offset) *first_bad_offset = side ? (long long)(b.second + i) : (long long)i - (long long)G;
+                    }
+                    fprintf(stderr, "ofri guard: block %p of %zu bytes: byte at offset %lld was overwritten (0x%02x)\n", b.first, b.second,
+                            side ? (long long)(b.second + i) : (long long)i - (long long)G, h[i]);
+                    *bad_blocks += 1;
+                    break;
+                }
+        }
+    return OFRI_OK;
+}
+
 extern "C" int ofri_pool_trim(ofri_ctx *ctx) {
     OFRI_TRY(ofri_check_ctx(ctx));
     OFRI_TRY(ofri_stream_wait(ctx));
     for (auto &kv : ctx->pool)
-        for (void *p : kv.second) (void)hipFree(p);
+        for (void *p : kv.second) pool_free(p);
     ctx->pool.clear();
     return OFRI_OK;
 }
@@ -81,8 +157,8 @@ extern "C" int ofri_ctx_destroy(ofri_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (auto &kv : ctx->pool)
-        for (void *p : kv.second) (void)hipFree(p);
-    for (auto &kv : ctx->live) (void)hipFree(kv.first);
+        for (void *p : kv.second) pool_free(p);
+    for (auto &kv : ctx->live) pool_free(kv.first);
     for (auto &r : ctx->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto &kv : ctx->tables) (void)hipFree(kv.second);
     if (ctx->red_partials) (void)hipFree(ctx->red_partials);
@@ -124,6 +200,7 @@ extern "C" int ofri_alloc(ofri_ctx *ctx, size_t bytes, void **dptr) {
             ci->second.pop_back();
             ctx->live[p] = rb;
             *dptr = p;
+            if (pool_poison()) OFRI_TRY(ofri_dev_fill(ctx, p, 0xFF, rb));
             return OFRI_OK;
         }
     }
@@ -133,17 +210,18 @@ extern "C" int ofri_alloc(ofri_ctx *ctx, size_t bytes, void **dptr) {
         it->second.pop_back();
     } else {
         OFRI_COUNT_ALLOC();
-        hipError_t e = hipMalloc(&p, rb);
+        hipError_t e = pool_malloc(&p, rb);
         if (e != hipSuccess) {
             // release cached blocks and retry once
             (void)ofri_pool_trim(ctx);
-            e = hipMalloc(&p, rb);
+            e = pool_malloc(&p, rb);
             if (e != hipSuccess) return ofri_set_error(OFRI_ENOMEM, "hipMalloc(%zu): %s", rb, hipGetErrorString(e));
         }
     }
     ctx->live[p] = rb;
     if (ctx->capturing) ctx->cap_blocks[p] = rb;
     *dptr = p;
+    if (pool_poison()) OFRI_TRY(ofri_dev_fill(ctx, p, 0xFF, rb));
     return OFRI_OK;
 }
 
@@ -166,7 +244,11 @@ extern "C" int ofri_free(ofri_ctx *ctx, void *dptr) {
     else if (gh != ctx->graph_held.end()) {           // a captured graph still writes this block: it stays the graph's
         gh->second->blocks.push_back({dptr, it->second});
         ctx->graph_held.erase(gh);
-    } else ctx->pool[it->second].push_back(dptr);
+    } else {
+        if (ctx->capturing && pool_poison())
+            fprintf(stderr, "ofri pool: block %p (%zu bytes), handed out before the capture, is freed during it\n", dptr, it->second);
+        ctx->pool[it->second].push_back(dptr);
+    }
     ctx->live.erase(it);
     return OFRI_OK;
 }
@@ -224,6 +306,14 @@ extern "C" int ofri_graph_launch(ofri_ctx *ctx, ofri_graph *graph) {
     OFRI_TRY(ofri_check_ctx(ctx));
     OFRI_REQUIRE(graph && graph->ctx == ctx, "the graph was captured on another context");
     OFRI_REQUIRE(!ctx->capturing, "a capture is running on this context");
+    if (pool_poison()) {            // debugging aid: the graph's own blocks must be nobody else's
+        for (auto &b : graph->blocks) {
+            if (ctx->live.count(b.first)) fprintf(stderr, "ofri pool: graph block %p (%zu bytes) is also handed out\n", b.first, b.second);
+            for (auto &kv : ctx->pool)
+                for (void *p : kv.second)
+                    if (p == b.first) fprintf(stderr, "ofri pool: graph block %p (%zu bytes) is also in the free list\n", b.first, b.second);
+        }
+    }
     OFRI_HIP(hipGraphLaunch(graph->exec, ctx->stream));
     return OFRI_OK;
 }
@@ -276,20 +366,98 @@ extern "C" int ofri_download(ofri_ctx *ctx, void *dst_host, const void *src, siz
     return OFRI_OK;
 }
 
+// ---- copies and fills as kernels (see ofri_internal.h) ------------------------------------------------------
+__global__ void __launch_bounds__(256) k_dev_copy16(uint4 *__restrict__ dst, const uint4 *__restrict__ src, size_t n16,
+                                                    unsigned char *__restrict__ dtail, const unsigned char *__restrict__ stail, int ntail) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t st = (size_t)gridDim.x * 256;
+    for (; i + 3 * st < n16; i += 4 * st) {          // four 16-byte moves in flight per thread
+        const uint4 a = src[i], b = src[i + st], c = src[i + 2 * st], d = src[i + 3 * st];
+        dst[i] = a; dst[i + st] = b; dst[i + 2 * st] = c; dst[i + 3 * st] = d;
+    }
+    for (; i < n16; i += st) dst[i] = src[i];
+    if (blockIdx.x == 0 && (int)threadIdx.x < ntail) dtail[threadIdx.x] = stail[threadIdx.x];
+}
+__global__ void __launch_bounds__(256) k_dev_copy1(unsigned char *__restrict__ dst, const unsigned char *__restrict__ src, size_t n) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (const size_t st = (size_t)gridDim.x * 256; i < n; i += st) dst[i] = src[i];
+}
+__global__ void __launch_bounds__(256) k_dev_copy4(unsigned *__restrict__ dst, const unsigned *__restrict__ src, size_t n) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (const size_t st = (size_t)gridDim.x * 256; i < n; i += st) dst[i] = src[i];
+}
+__global__ void __launch_bounds__(256) k_dev_fill16(uint4 *__restrict__ dst, size_t n16, unsigned v, unsigned char *__restrict__ dtail, int ntail) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const uint4 q = make_uint4(v, v, v, v);
+    for (const size_t st = (size_t)gridDim.x * 256; i < n16; i += st) dst[i] = q;
+    if (blockIdx.x == 0 && (int)threadIdx.x < ntail) dtail[threadIdx.x] = (unsigned char)v;
+}
+__global__ void __launch_bounds__(256) k_dev_fill1(unsigned char *__restrict__ dst, size_t n, unsigned char v) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (const size_t st = (size_t)gridDim.x * 256; i < n; i += st) dst[i] = v;
+}
+// one workgroup row per plane row: 4-byte elements (planes whose widths or pitches are not multiples of 16 bytes)
+__global__ void __launch_bounds__(256) k_dev_copy2d(unsigned *__restrict__ dst, size_t dpitch4, const unsigned *__restrict__ src, size_t spitch4,
+                                                    int width4, int rows) {
+    for (int y = blockIdx.y; y < rows; y += gridDim.y)
+        for (int x = blockIdx.x * 256 + threadIdx.x; x < width4; x += gridDim.x * 256) dst[(size_t)y * dpitch4 + x] = src[(size_t)y * spitch4 + x];
+}
+
+static int copy_grid(size_t units) {
+    size_t g = (units + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+int ofri_dev_copy(ofri_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (!bytes || dst == src) return OFRI_OK;
+    if (((((size_t)dst) | ((size_t)src)) & 15) == 0) {
+        const size_t n16 = bytes / 16;
+        const int tail = (int)(bytes - 16 * n16);
+        k_dev_copy16<<<copy_grid((n16 + 3) / 4), 256, 0, ctx->stream>>>((uint4 *)dst, (const uint4 *)src, n16, (unsigned char *)dst + 16 * n16,
+                                                                         (const unsigned char *)src + 16 * n16, tail);
+    } else if (((((size_t)dst) | ((size_t)src) | bytes) & 3) == 0) {
+        k_dev_copy4<<<copy_grid(bytes / 4), 256, 0, ctx->stream>>>((unsigned *)dst, (const unsigned *)src, bytes / 4);
+    } else {
+        k_dev_copy1<<<copy_grid(bytes), 256, 0, ctx->stream>>>((unsigned char *)dst, (const unsigned char *)src, bytes);
+    }
+    OFRI_LAUNCH_CHECK();
+    return OFRI_OK;
+}
+
+int ofri_dev_fill(ofri_ctx *ctx, void *dst, unsigned char value, size_t bytes) {
+    if (!bytes) return OFRI_OK;
+    if ((((size_t)dst) & 15) == 0) {
+        const size_t n16 = bytes / 16;
+        const int tail = (int)(bytes - 16 * n16);
+        k_dev_fill16<<<copy_grid(n16), 256, 0, ctx->stream>>>((uint4 *)dst, n16, 0x01010101u * value, (unsigned char *)dst + 16 * n16, tail);
+    } else {
+        k_dev_fill1<<<copy_grid(bytes), 256, 0, ctx->stream>>>((unsigned char *)dst, bytes, value);
+    }
+    OFRI_LAUNCH_CHECK();
+    return OFRI_OK;
+}
+
+int ofri_dev_copy2d(ofri_ctx *ctx, void *dst, size_t dpitch, const void *src, size_t spitch, size_t width_bytes, size_t rows) {
+    if (!width_bytes || !rows) return OFRI_OK;
+    OFRI_REQUIRE(((((size_t)dst) | ((size_t)src) | dpitch | spitch | width_bytes) & 3) == 0, "pitched copy of rows that are not whole 4-byte words");
+    OFRI_REQUIRE(rows <= 0x7fffffff && width_bytes / 4 <= 0x7fffffff, "pitched copy too large");
+    const int w4 = (int)(width_bytes / 4);
+    dim3 g((unsigned)((w4 + 255) / 256 > 64 ? 64 : (w4 + 255) / 256), (unsigned)(rows > 4096 ? 4096 : rows));
+    k_dev_copy2d<<<g, 256, 0, ctx->stream>>>((unsigned *)dst, dpitch / 4, (const unsigned *)src, spitch / 4, w4, (int)rows);
+    OFRI_LAUNCH_CHECK();
+    return OFRI_OK;
+}
+
 extern "C" int ofri_copy(ofri_ctx *ctx, void *dst, const void *src, size_t bytes) {
     OFRI_TRY(ofri_check_ctx(ctx));
     OFRI_REQUIRE(dst && src, "null pointer");
-    if (!bytes) return OFRI_OK;
-    OFRI_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
-    return OFRI_OK;
+    return ofri_dev_copy(ctx, dst, src, bytes);
 }
 
 extern "C" int ofri_zero(ofri_ctx *ctx, void *dst, size_t bytes) {
     OFRI_TRY(ofri_check_ctx(ctx));
     OFRI_REQUIRE(dst, "null pointer");
-    if (!bytes) return OFRI_OK;
-    OFRI_HIP(hipMemsetAsync(dst, 0, bytes, ctx->stream));
-    return OFRI_OK;
+    return ofri_dev_fill(ctx, dst, 0, bytes);
 }
 
 int ofri_upload_table(ofri_ctx *ctx, PoolBuf &buf, const void *host, size_t bytes) {

@@ -169,7 +169,7 @@ extern "C" int ofri_gauss_sep(ofri_ctx *ctx, const float *src, float *dst, int r
             else if (ntaps == 5) k_gauss_vec4<5><<<gv, bv, 0, ctx->stream>>>(src, o, rows, cols, t);
             else k_gauss_vec4<7><<<gv, bv, 0, ctx->stream>>>(src, o, rows, cols, t);
             OFRI_LAUNCH_CHECK();
-            if (o != dst) OFRI_HIP(hipMemcpyAsync(dst, o, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+            if (o != dst) OFRI_TRY(ofri_dev_copy(ctx, dst, o, bytes));
             return OFRI_OK;
         }
         dim3 b(64, 4), g(ceil_div(cols, GT_X), ceil_div(rows, GT_Y));
@@ -177,7 +177,7 @@ extern "C" int ofri_gauss_sep(ofri_ctx *ctx, const float *src, float *dst, int r
         else if (ntaps == 5) k_gauss_fused<5><<<g, b, 0, ctx->stream>>>(src, o, rows, cols, t);
         else k_gauss_fused<7><<<g, b, 0, ctx->stream>>>(src, o, rows, cols, t);
         OFRI_LAUNCH_CHECK();
-        if (o != dst) OFRI_HIP(hipMemcpyAsync(dst, o, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+        if (o != dst) OFRI_TRY(ofri_dev_copy(ctx, dst, o, bytes));
     } else {
         dim3 b(64, 4), g(ceil_div(cols, 64), ceil_div(rows, 4));
         k_gauss_pass<1><<<g, b, 0, ctx->stream>>>(src, tmp.as<float>(), rows, cols, ntaps, t);

@@ -287,8 +287,8 @@ static int hs_iterate_padded(ofri_ctx *ctx, const float *Uin, const float *Vin, 
     float *U[2] = {base, base + 2 * plane}, *V[2] = {base + plane, base + 3 * plane};
     float *A = base + 4 * plane, *B = base + 5 * plane, *C = base + 6 * plane;
     OFRI_REQUIRE((((size_t)base) & 15) == 0, "pool block is not 16-byte aligned");
-    OFRI_HIP(hipMemcpy2DAsync(U[0], pbytes, Uin, wbytes, wbytes, rows, hipMemcpyDeviceToDevice, ctx->stream));
-    OFRI_HIP(hipMemcpy2DAsync(V[0], pbytes, Vin, wbytes, wbytes, rows, hipMemcpyDeviceToDevice, ctx->stream));
+    OFRI_TRY(ofri_dev_copy2d(ctx, U[0], pbytes, Uin, wbytes, wbytes, rows));
+    OFRI_TRY(ofri_dev_copy2d(ctx, V[0], pbytes, Vin, wbytes, wbytes, rows));
     OFRI_TRY(ofri_hs_scaled_coefs(ctx, frames ? nullptr : fx, fy, ft, fx, fy, A, B, C, a2, rows, cols, P));
     int Tmax = ofri_hs_fused_max_sweeps();
     if (ctx->hs_fuse > 1 && ctx->hs_fuse < Tmax) Tmax = ctx->hs_fuse;
@@ -303,8 +303,8 @@ static int hs_iterate_padded(ofri_ctx *ctx, const float *Uin, const float *Vin, 
         remaining -= T;
     }
     OFRI_TRY(prof_end(ctx, rec, rows, cols, L, niter));
-    OFRI_HIP(hipMemcpy2DAsync(Uout, wbytes, U[cur], pbytes, wbytes, rows, hipMemcpyDeviceToDevice, ctx->stream));
-    OFRI_HIP(hipMemcpy2DAsync(Vout, wbytes, V[cur], pbytes, wbytes, rows, hipMemcpyDeviceToDevice, ctx->stream));
+    OFRI_TRY(ofri_dev_copy2d(ctx, Uout, wbytes, U[cur], pbytes, wbytes, rows));
+    OFRI_TRY(ofri_dev_copy2d(ctx, Vout, wbytes, V[cur], pbytes, wbytes, rows));
     return OFRI_OK;
 }
 
@@ -318,8 +318,8 @@ static int hs_iterate_io(ofri_ctx *ctx, const float *Uin, const float *Vin, floa
                          float *work = nullptr) {
     const size_t bytes = (size_t)rows * cols * sizeof(float);
     if (niter == 0) {
-        if (Uin != Uout) OFRI_HIP(hipMemcpyAsync(Uout, Uin, bytes, hipMemcpyDeviceToDevice, ctx->stream));
-        if (Vin != Vout) OFRI_HIP(hipMemcpyAsync(Vout, Vin, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+        if (Uin != Uout) OFRI_TRY(ofri_dev_copy(ctx, Uout, Uin, bytes));
+        if (Vin != Vout) OFRI_TRY(ofri_dev_copy(ctx, Vout, Vin, bytes));
         return OFRI_OK;
     }
     const float a2 = alpha * alpha;         // alpha is a float32 in the reference's compiled signature
@@ -377,8 +377,8 @@ static int hs_iterate_io(ofri_ctx *ctx, const float *Uin, const float *Vin, floa
     }
     OFRI_TRY(prof_end(ctx, rec, rows, cols, L, niter));
     if (su != Uout) {
-        OFRI_HIP(hipMemcpyAsync(Uout, su, bytes, hipMemcpyDeviceToDevice, ctx->stream));
-        OFRI_HIP(hipMemcpyAsync(Vout, sv, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+        OFRI_TRY(ofri_dev_copy(ctx, Uout, su, bytes));
+        OFRI_TRY(ofri_dev_copy(ctx, Vout, sv, bytes));
     }
     return OFRI_OK;
 }
@@ -411,8 +411,8 @@ static int hs_compute_impl(ofri_ctx *ctx, const float *frame0, const float *fram
         float *z0, *z1;
         if (work) { z0 = work; z1 = work + wplane; }
         else { OFRI_TRY(zu.get(bytes)); OFRI_TRY(zv.get(bytes)); z0 = zu.as<float>(); z1 = zv.as<float>(); }
-        OFRI_HIP(hipMemsetAsync(z0, 0, bytes, ctx->stream));
-        OFRI_HIP(hipMemsetAsync(z1, 0, bytes, ctx->stream));
+        OFRI_TRY(ofri_dev_fill(ctx, z0, 0, bytes));
+        OFRI_TRY(ofri_dev_fill(ctx, z1, 0, bytes));
         U_in = z0; V_in = z1;
     }
     if (n_stream > 0) {

@@ -430,8 +430,8 @@ int ofri_sl_fill(ofri_ctx *ctx, OfriSlSet &s, const float *U, const float *V, co
     const size_t bytes = (size_t)H * W * sizeof(float);
     s.zero_in = U == nullptr;
     if (U) {
-        OFRI_HIP(hipMemcpyAsync(s.U[0], U, bytes, hipMemcpyDeviceToDevice, ctx->stream));
-        OFRI_HIP(hipMemcpyAsync(s.V[0], V, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+        OFRI_TRY(ofri_dev_copy(ctx, s.U[0], U, bytes));
+        OFRI_TRY(ofri_dev_copy(ctx, s.V[0], V, bytes));
     }
     return ofri_hs_scaled_coefs(ctx, fx, fy, ft, first, second, s.fx, s.fy, s.ft, a2, H, W);
 }

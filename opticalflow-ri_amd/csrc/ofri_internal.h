@@ -104,6 +104,16 @@ struct PoolBuf {
     template <class T> T *as() { return static_cast<T *>(p); }
 };
 
+// Device-to-device copies and fills as kernels on the context's stream.  The library never enqueues hipMemsetAsync /
+// hipMemcpyAsync(DeviceToDevice) itself: inside a captured graph those become memset / memcpy nodes, which the runtime may
+// hand to another engine than the kernel nodes around them, and replays of such graphs were seen to run a fill after
+// the kernel that overwrote its destination (several contexts replaying on streams of one pool).  Kernel nodes of one
+// stream keep their order.  bytes may be any number; 16-byte moves where both pointers allow it.
+int ofri_dev_copy(ofri_ctx *ctx, void *dst, const void *src, size_t bytes);
+int ofri_dev_fill(ofri_ctx *ctx, void *dst, unsigned char value, size_t bytes);
+// rows of width_bytes (a multiple of 4, pointers and pitches 4-byte aligned) between pitched planes
+int ofri_dev_copy2d(ofri_ctx *ctx, void *dst, size_t dpitch, const void *src, size_t spitch, size_t width_bytes, size_t rows);
+
 // upload a small host table into a pooled device block (stream-ordered; the host copy is staged
 // before returning because pageable hipMemcpyAsync completes its host read before it returns)
 int ofri_upload_table(ofri_ctx *ctx, PoolBuf &buf, const void *host, size_t bytes);

@@ -732,8 +732,8 @@ extern "C" int ofri_ls_compute(ofri_ctx *ctx, const float *im1, const float *im2
     // the first block reads the caller's arrays where they are, unless the output would overwrite them
     int first_src = LS_IN;
     if (u_out == u_in || u_out == v_in || v_out == u_in || v_out == v_in) {
-        OFRI_HIP(hipMemcpyAsync(bufs.u[0], u_in, bytes, hipMemcpyDeviceToDevice, ctx->stream));
-        OFRI_HIP(hipMemcpyAsync(bufs.v[0], v_in, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+        OFRI_TRY(ofri_dev_copy(ctx, bufs.u[0], u_in, bytes));
+        OFRI_TRY(ofri_dev_copy(ctx, bufs.v[0], v_in, bytes));
         first_src = 0;
     }
     {   // im / max(im) per image, coefficient fields, loop state

@@ -442,7 +442,7 @@ extern "C" int ofri_lk_compute(ofri_ctx *ctx, const float *im1, const float *im2
         PoolBuf lst(ctx);
         OFRI_TRY(lst.get((n + 1) * sizeof(unsigned)));
         unsigned *count = lst.as<unsigned>(), *list = count + 1;
-        OFRI_HIP(hipMemsetAsync(count, 0, sizeof(unsigned), ctx->stream));
+        OFRI_TRY(ofri_dev_fill(ctx, count, 0, sizeof(unsigned)));
         const int tiles_x = ceil_div(cols, LKT_PX), tiles = tiles_x * ceil_div(rows, LKT_PY);
         k_lk_tile<<<tiles, 256, 0, ctx->stream>>>(im1, im2, U_in, V_in, U_out, V_out, rows, cols, niter, tiles_x, list, count);
         OFRI_LAUNCH_CHECK();

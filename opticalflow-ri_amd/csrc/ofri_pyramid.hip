@@ -229,7 +229,7 @@ static int resize_generic(ofri_ctx *ctx, const float *src, int rows_in, int cols
     OFRI_REQUIRE(src != dst, "resize cannot run in place");
     const bool need_h = cols_out != cols_in, need_v = rows_out != rows_in;
     if (!need_h && !need_v) {
-        OFRI_HIP(hipMemcpyAsync(dst, src, (size_t)rows_in * cols_in * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+        OFRI_TRY(ofri_dev_copy(ctx, dst, src, (size_t)rows_in * cols_in * sizeof(float)));
         return OFRI_OK;
     }
     dim3 b(64, 4);

@@ -69,8 +69,8 @@ extern "C" int ofri_warp_shift_ofe(ofri_ctx *ctx, const float *im, const float *
     PoolBuf win(ctx), dU(ctx), dV(ctx), shifted(ctx), oob(ctx);
     OFRI_TRY(win.get(bytes)); OFRI_TRY(dU.get(bytes)); OFRI_TRY(dV.get(bytes));
     OFRI_TRY(shifted.get(bytes)); OFRI_TRY(oob.get(2 * sizeof(int)));
-    OFRI_HIP(hipMemsetAsync(win.p, 0xFF, bytes, ctx->stream));             // -1: nothing landed here
-    OFRI_HIP(hipMemsetAsync(oob.p, 0x7F, 2 * sizeof(int), ctx->stream));   // 0x7F7F7F7F: no offender
+    OFRI_TRY(ofri_dev_fill(ctx, win.p, 0xFF, bytes));             // -1: nothing landed here
+    OFRI_TRY(ofri_dev_fill(ctx, oob.p, 0x7F, 2 * sizeof(int)));   // 0x7F7F7F7F: no offender
     dim3 b(64, 4), g(ceil_div(W, 64), ceil_div(H, 4));
     k_shift_vote<<<g, b, 0, ctx->stream>>>(U, V, win.as<int>(), dU.as<float>(), dV.as<float>(), oob.as<int>(), H, W);
     OFRI_LAUNCH_CHECK();
