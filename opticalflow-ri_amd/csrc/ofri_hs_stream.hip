@@ -37,7 +37,7 @@ template <int NL, int LN = 32> struct SlCfg {
     static constexpr int CR = LAG;                   // coefficient ring rows: rows rho-(LAG-1) .. rho are live
     static constexpr int THREADS = NS * LN + 2 * LN;     // + the loader: two sets of LN lanes (U, A, C and V, B)
     // workgroups per CU that the LDS (LN = 32: 40 KB each at NL = 12, 52 KB at 16) and 128 registers allow
-    static constexpr int PER_CU = LN == 64 ? (NL == 12 ? 2 : 1) : (NL == 12 ? 4 : 3);
+    static constexpr int PER_CU = LN == 64 ? (NL == 12 ? 2 : 1) : (NL == 12 ? 4 : 3);      // (16 deep in wide strips: 106 KB of LDS, one)
     static constexpr int MIN_CHUNK = 128;            // chunk rows below which one workgroup per CU fewer is launched
 };
 #define SL_NL_MAIN 12
@@ -286,7 +286,7 @@ __device__ __forceinline__ void sl_loader(const SlPlanes &in, float4 (&ring)[SlC
 // (Uo, Vo) hold.  All planes are dense with W columns (W % 4 == 0, 16-byte aligned); zero_in: the input flow is
 // zero and in.U, in.V are not read.
 template <int NL, bool FULL, bool ACC, int LN = 32>
-__global__ void __launch_bounds__((SlCfg<NL, LN>::THREADS), (LN == 64 ? 2 : 1))
+__global__ void __launch_bounds__((SlCfg<NL, LN>::THREADS), (LN == 64 && NL == 12 ? 2 : 1))
 k_hs_stream(SlPlanes in, float *__restrict__ Uo, float *__restrict__ Vo, int H, int W, int T, int tiles_x, int chunk_rows,
             int zero_in, OfriPrio pr) {
     constexpr int SL_NS = SlCfg<NL, LN>::NS, SL_CR = SlCfg<NL, LN>::CR, SL_LAG = SlCfg<NL, LN>::LAG, SL_OX = SlCfg<NL, LN>::OX, SL_NL = NL;
@@ -499,7 +499,10 @@ int ofri_sl_sweeps(ofri_ctx *ctx, OfriSlSet &s, int n, bool to_dense, bool accum
         const bool dense = remaining == T && to_dense;
         SlPlanes in{s.U[c], s.V[c], s.fx, s.fy, s.ft};
         float *uo = dense ? Uout : s.U[c ^ 1], *vo = dense ? Vout : s.V[c ^ 1];
-        if (deep) sl_launch<SL_NL_DEEP, 32>(ctx, in, uo, vo, H, W, T, s.zero_in, dense && accumulate);
+        // the deep launch in strips of 256 columns (eight stage wavefronts and two loaders, 106 KB of LDS, one workgroup per
+        // CU) where the 12-sweep launches take them too: 16 sweeps at 4096 x 4096 in 180 us against 225 us in narrow strips
+        if (deep && sl_wide_pays(ctx, H, W)) sl_launch<SL_NL_DEEP, 64>(ctx, in, uo, vo, H, W, T, s.zero_in, dense && accumulate);
+        else if (deep) sl_launch<SL_NL_DEEP, 32>(ctx, in, uo, vo, H, W, T, s.zero_in, dense && accumulate);
         else if (sl_wide_pays(ctx, H, W)) sl_launch<SL_NL_MAIN, 64>(ctx, in, uo, vo, H, W, T, s.zero_in, dense && accumulate);
         else sl_launch<SL_NL_MAIN, 32>(ctx, in, uo, vo, H, W, T, s.zero_in, dense && accumulate);
         OFRI_LAUNCH_CHECK();
