@@ -29,18 +29,29 @@
 // LN: lanes of a stage, 32 (a stage is half a wavefront, strips of 128 columns) or 64 (a whole wavefront, strips of 256
 // columns: the sweeps' lost columns are 24 of 256 instead of 24 of 128, at twice the LDS per workgroup; pays where the
 // row chunks stay long with two workgroups per CU, i.e. on 4096 x 4096 fields).
-template <int NL, int LN = 32> struct SlCfg {
-    static constexpr int NS = NL / 2;                // pipeline stages
+// K: sweeps per stage.  A stage keeps two rows per sweep and the coefficients of its last K - 1 rows in registers; per step it
+// reads one row and one row of coefficients from LDS and writes one row, whatever K is, so the LDS traffic per sweep (which
+// is what a step costs before any arithmetic: 47 KB per step and workgroup at K = 2 in wide strips, at 128 bytes per clock
+// and CU) falls with 1 / K, against more registers per stage (K = 3: about 150).
+template <int NL, int LN = 32, int K = 2> struct SlCfg {
+    static_assert(NL % K == 0, "whole stages");
+    static constexpr int NS = NL / K;                // pipeline stages
     static constexpr int RX = 4 * LN;                // strip width
     static constexpr int OX = RX - 2 * NL;           // stored width: the sweeps eat NL columns on each side
-    static constexpr int LAG = 3 * NS;               // the last stage's second sweep runs this many rows behind the loader
+    static constexpr int LAG = (K + 1) * NS;         // the last stage's last sweep runs this many rows behind the loader
     static constexpr int CR = LAG;                   // coefficient ring rows: rows rho-(LAG-1) .. rho are live
-    static constexpr int THREADS = NS * LN + 2 * LN;     // + the loader: two sets of LN lanes (U, A, C and V, B)
-    // workgroups per CU that the LDS (LN = 32: 40 KB each at NL = 12, 52 KB at 16) and 128 registers allow
-    static constexpr int PER_CU = LN == 64 ? (NL == 12 ? 2 : 1) : (NL == 12 ? 4 : 3);      // (16 deep in wide strips: 106 KB of LDS, one)
+    static constexpr int THREADS = (NS * LN + 63) / 64 * 64 + 2 * LN;     // stages (whole wavefronts) + the loader: two sets of LN lanes (U, A, C and V, B)
+    static constexpr int LDS = (NS * 2 * 2 + CR * 3) * LN * 16;
+    // workgroups per CU that the LDS (K = 2, LN = 32: 40 KB each at NL = 12, 52 KB at 16) and the registers allow (K = 2: 128,
+    // four wavefronts per SIMD; K = 3: 168, three)
+    static constexpr int PER_CU = K == 2 ? (LN == 64 ? (NL == 12 ? 2 : 1) : (NL == 12 ? 4 : 3))      // (16 deep in wide strips: 106 KB of LDS, one)
+                                         : (LN == 64 ? 2 : 4);
     static constexpr int MIN_CHUNK = 128;            // chunk rows below which one workgroup per CU fewer is launched
 };
 #define SL_NL_MAIN 12
+#ifndef SL_K_MAIN
+#define SL_K_MAIN 2                      // sweeps per stage of the 12-sweep launches
+#endif
 #define SL_NL_DEEP 16
 
 __device__ __forceinline__ float sl_left(float v) {     // lane-1 (wave_shr:1)
@@ -145,27 +156,27 @@ __device__ __forceinline__ SlRow sl_sweep(const SlRow &a, const SlRow &c, const 
     return o;
 }
 
-struct SlStage {                 // registers of one pipeline stage (one lane)
-    SlRow in0, in1;              // input rows rA-1, rA
-    SlRow mid0, mid1;            // rows rA-2, rA-1 of the stage's first sweep
-    SlCoef gprev;                // coefficients of row rA-1
+template <int K> struct SlStage {    // registers of one pipeline stage (one lane)
+    SlRow r0[K], r1[K];              // sweep j of the stage (0-based) makes row rA-j: r0[j], r1[j] are rows rA-j-1, rA-j of its input
+    SlCoef gp[K > 1 ? K - 1 : 1];    // coefficients of rows rA-1 .. rA-(K-1)
     float4 au0, av0, au1, av1, au2, av2;   // (accumulating store) what the destination holds in the next three rows to store
-    int rA;                      // row the first sweep produces at this step
-    int cslot;                   // coefficient ring slot of row rA
+    int rA;                          // row the first sweep produces at this step
+    int cslot;                       // coefficient ring slot of row rA
 };
 
-// one step of a stage: first sweep at row rA, second sweep at row rA-1.  ACC: the last stage adds its row to what the
-// destination holds; those values are fetched three steps (rows) ahead by every lane of the wavefront that holds the last
-// stage (LASTW), from addresses clamped into the chunk (accU, accV: the row three below rowU, rowV; lane_safe: the lane's
-// columns clamped into the image), so that the loads are unconditional: a conditional load makes the rotation of the
-// three registers a real move, which waits for the load just issued, and the compiler then waits for every store as well.
-template <int NL, int LN, bool FULL, bool ACC, bool LASTW>
-__device__ __forceinline__ void sl_stage_step(SlStage &st, float4 (&ring)[SlCfg<NL, LN>::NS][2][2][LN],
-                                              float4 (&coef)[SlCfg<NL, LN>::CR][3][LN], int stage, int l, bool passA, bool passB,
+// one step of a stage: sweep j at row rA-j, j = 0 .. K-1, each from the row the sweep before it has just made.  ACC: the last
+// stage adds its row to what the destination holds; those values are fetched three steps (rows) ahead by every lane of the
+// wavefront that holds the last stage (LASTW), from addresses clamped into the chunk (accU, accV: the row three below rowU,
+// rowV; lane_safe: the lane's columns clamped into the image), so that the loads are unconditional: a conditional load makes
+// the rotation of the three registers a real move, which waits for the load just issued, and the compiler then waits for
+// every store as well.
+template <int NL, int LN, int K, bool FULL, bool ACC, bool LASTW>
+__device__ __forceinline__ void sl_stage_step(SlStage<K> &st, float4 (&ring)[SlCfg<NL, LN, K>::NS][2][2][LN],
+                                              float4 (&coef)[SlCfg<NL, LN, K>::CR][3][LN], int stage, int l, const bool (&pass)[K], bool all_pass,
                                               bool store_lane, int lane_off, float *__restrict__ rowU, float *__restrict__ rowV,
                                               bool row_ok, const float *__restrict__ accU, const float *__restrict__ accV, int lane_safe,
                                               bool idle, f2 w12) {
-    constexpr int SL_NS = SlCfg<NL, LN>::NS, SL_CR = SlCfg<NL, LN>::CR;
+    constexpr int SL_NS = SlCfg<NL, LN, K>::NS, SL_CR = SlCfg<NL, LN, K>::CR;
     // newest input row rA+1, written one step ago
     // ring and coefficient rows hold a lane's pixels interleaved: [0] = u0 v0 u1 v1 (A0 B0 A1 B1), [1] = u2 v2 u3 v3
     const float4 n01 = ring[stage][(st.rA + 1) & 1][0][l], n23 = ring[stage][(st.rA + 1) & 1][1][l];
@@ -176,20 +187,20 @@ __device__ __forceinline__ void sl_stage_step(SlStage &st, float4 (&ring)[SlCfg<
         g.c[0] = gc.x; g.c[1] = gc.y; g.c[2] = gc.z; g.c[3] = gc.w;
     }
     st.cslot = st.cslot + 1 == SL_CR ? 0 : st.cslot + 1;
-    SlRow nw;
-    sl_unpack(n01, n23, nw.p);
-    SlRow mid2, out;
-    if (idle || (!FULL && __builtin_amdgcn_ballot_w64(!(passA && passB)) == 0)) {
+    SlRow x[K + 1];                  // x[j]: the newest row of sweep j's input; x[K]: the row this stage hands on
+    sl_unpack(n01, n23, x[0].p);
+    if (idle || (!FULL && __builtin_amdgcn_ballot_w64(!all_pass) == 0)) {
         // idle: the rows this wavefront's stages would make at this step are outside what the chunk's result depends on
-        // (the pipeline is filling or draining); or neither stage of this wavefront has a sweep to do (fewer sweeps asked
+        // (the pipeline is filling or draining); or no stage of this wavefront has a sweep to do (fewer sweeps asked
         // than the pipeline is deep): hand the rows on untouched
-        mid2 = st.in1;
-        out = st.mid1;
+#pragma unroll
+        for (int j = 0; j < K; ++j) x[j + 1] = st.r1[j];
     } else {
-        mid2 = sl_sweep<FULL>(st.in0, st.in1, nw, g, passA, w12);              // row rA of the first sweep
-        out = sl_sweep<FULL>(st.mid0, st.mid1, mid2, st.gprev, passB, w12);    // row rA-1 of the second sweep
+#pragma unroll
+        for (int j = 0; j < K; ++j) x[j + 1] = sl_sweep<FULL>(st.r0[j], st.r1[j], x[j], j == 0 ? g : st.gp[j > 0 ? j - 1 : 0], pass[j], w12);    // row rA-j of sweep j
     }
-    const int rB = st.rA - 1;
+    const SlRow &out = x[K];
+    const int rB = st.rA - (K - 1);
     float4 a0u, a0v;
     if (ACC && LASTW) {
         a0u = st.au0; a0v = st.av0;
@@ -212,9 +223,11 @@ __device__ __forceinline__ void sl_stage_step(SlStage &st, float4 (&ring)[SlCfg<
             *reinterpret_cast<float4 *>(rowV + lane_off) = ov;
         }
     }
-    st.in0 = st.in1; st.in1 = nw;
-    st.mid0 = st.mid1; st.mid1 = mid2;
-    st.gprev = g;
+#pragma unroll
+    for (int j = 0; j < K; ++j) { st.r0[j] = st.r1[j]; st.r1[j] = x[j]; }
+#pragma unroll
+    for (int j = K - 2; j > 0; --j) st.gp[j] = st.gp[j - 1];
+    if (K > 1) st.gp[0] = g;
     ++st.rA;
 }
 
@@ -232,11 +245,11 @@ __device__ __forceinline__ float4 sl_load4(const float *__restrict__ row, const 
 // U, A, C; set 1 carries V, B (each one plane after its partner, so the row address is a scalar base plus a per-lane
 // offset).  Rows outside the image are the reflected rows.  EDGE: the strip reaches over the left or right edge of
 // the image.  ZERO: the flow is zero on input and is not read.
-template <int NL, int LN, bool EDGE, bool ZERO>
-__device__ __forceinline__ void sl_loader(const SlPlanes &in, float4 (&ring)[SlCfg<NL, LN>::NS][2][2][LN],
-                                          float4 (&coef)[SlCfg<NL, LN>::CR][3][LN], int ltid, int x0, int rho0, int NS, int H, int W,
+template <int NL, int LN, int K, bool EDGE, bool ZERO>
+__device__ __forceinline__ void sl_loader(const SlPlanes &in, float4 (&ring)[SlCfg<NL, LN, K>::NS][2][2][LN],
+                                          float4 (&coef)[SlCfg<NL, LN, K>::CR][3][LN], int ltid, int x0, int rho0, int NS, int H, int W,
                                           const OfriPrio &pr) {
-    constexpr int SL_CR = SlCfg<NL, LN>::CR;
+    constexpr int SL_CR = SlCfg<NL, LN, K>::CR;
     const int lj = ltid % LN, lset = ltid / LN;                        // ltid: thread index within the loader
     const int lx = x0 + 4 * lj;
     SlCols cols;                                                       // column reflection does not depend on the row
@@ -285,16 +298,18 @@ __device__ __forceinline__ void sl_loader(const SlPlanes &in, float4 (&ring)[SlC
 // FULL: all NL sweeps are wanted (no copy-through selects in the inner loop).  ACC: the result is added to what
 // (Uo, Vo) hold.  All planes are dense with W columns (W % 4 == 0, 16-byte aligned); zero_in: the input flow is
 // zero and in.U, in.V are not read.
-template <int NL, bool FULL, bool ACC, int LN = 32>
-__global__ void __launch_bounds__((SlCfg<NL, LN>::THREADS), (LN == 64 && NL == 12 ? 2 : 1))
+template <int NL, bool FULL, bool ACC, int LN = 32, int K = 2>
+__global__ void __launch_bounds__((SlCfg<NL, LN, K>::THREADS), (K == 2 ? (LN == 64 && NL == 12 ? 2 : 1) : (SlCfg<NL, LN, K>::PER_CU)))
 k_hs_stream(SlPlanes in, float *__restrict__ Uo, float *__restrict__ Vo, int H, int W, int T, int tiles_x, int chunk_rows,
             int zero_in, OfriPrio pr) {
-    constexpr int SL_NS = SlCfg<NL, LN>::NS, SL_CR = SlCfg<NL, LN>::CR, SL_LAG = SlCfg<NL, LN>::LAG, SL_OX = SlCfg<NL, LN>::OX, SL_NL = NL;
-    constexpr int SL_RX = SlCfg<NL, LN>::RX;
+    using Cfg = SlCfg<NL, LN, K>;
+    constexpr int SL_NS = Cfg::NS, SL_CR = Cfg::CR, SL_LAG = Cfg::LAG, SL_OX = Cfg::OX, SL_NL = NL;
+    constexpr int SL_RX = Cfg::RX;
+    static_assert(Cfg::LDS * Cfg::PER_CU <= 160 * 1024, "the workgroups per CU must fit the LDS");
     __shared__ float4 ring[SL_NS][2][2][LN];      // ring[s]: input rows of stage s.  [row & 1][U|V][lane]
     __shared__ float4 coef[SL_CR][3][LN];         // [row slot][A|B|C][lane]
-    constexpr int SL_NW = SlCfg<NL, LN>::THREADS / 64, SL_NLW = 2 * LN / 64;
-    static_assert(SlCfg<NL, LN>::THREADS % 64 == 0, "whole wavefronts");
+    constexpr int SL_NW = Cfg::THREADS / 64, SL_NLW = 2 * LN / 64;
+    static_assert(Cfg::THREADS % 64 == 0 && (SL_NS * LN) % 64 == 0, "whole wavefronts");
     __shared__ int wave_simd[SL_NW];
     // thread index by role: stages first, then the loader (sl_wave_role)
     const int tid = sl_wave_role<SL_NW, SL_NLW>(wave_simd, pr.ncu > 0 ? blockIdx.x / pr.ncu : 0) * 64 + (threadIdx.x & 63);
@@ -326,45 +341,50 @@ k_hs_stream(SlPlanes in, float *__restrict__ Uo, float *__restrict__ Vo, int H, 
     if (tid >= SL_NS * LN) {
         const bool edge = x0 < 0 || x0 + SL_RX > W;
         if (edge) {
-            if (zero_in) sl_loader<NL, LN, true, true>(in, ring, coef, tid - SL_NS * LN, x0, rho0, NS, H, W, pr);
-            else sl_loader<NL, LN, true, false>(in, ring, coef, tid - SL_NS * LN, x0, rho0, NS, H, W, pr);
+            if (zero_in) sl_loader<NL, LN, K, true, true>(in, ring, coef, tid - SL_NS * LN, x0, rho0, NS, H, W, pr);
+            else sl_loader<NL, LN, K, true, false>(in, ring, coef, tid - SL_NS * LN, x0, rho0, NS, H, W, pr);
         } else {
-            if (zero_in) sl_loader<NL, LN, false, true>(in, ring, coef, tid - SL_NS * LN, x0, rho0, NS, H, W, pr);
-            else sl_loader<NL, LN, false, false>(in, ring, coef, tid - SL_NS * LN, x0, rho0, NS, H, W, pr);
+            if (zero_in) sl_loader<NL, LN, K, false, true>(in, ring, coef, tid - SL_NS * LN, x0, rho0, NS, H, W, pr);
+            else sl_loader<NL, LN, K, false, false>(in, ring, coef, tid - SL_NS * LN, x0, rho0, NS, H, W, pr);
         }
     } else {
         // ---- stage half-wavefronts ---------------------------------------------------------------------
         const int stage = tid / LN, l = tid % LN;
-        SlStage st;
+        SlStage<K> st;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            st.in0.p[k] = st.in1.p[k] = st.mid0.p[k] = st.mid1.p[k] = st.gprev.ab[k] = (f2){0.f, 0.f};
-            st.gprev.c[k] = 0.f;
-        }
+        for (int j = 0; j < K; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                st.r0[j].p[k] = st.r1[j].p[k] = (f2){0.f, 0.f};
+                st.gp[j > 0 ? j - 1 : 0].ab[k] = (f2){0.f, 0.f};
+                st.gp[j > 0 ? j - 1 : 0].c[k] = 0.f;
+            }
         const f2 w12 = hs_w12_pair();
         st.au0 = st.av0 = st.au1 = st.av1 = st.au2 = st.av2 = make_float4(0.f, 0.f, 0.f, 0.f);
-        st.rA = rho0 - 2 - 3 * stage;
+        st.rA = rho0 - 2 - (K + 1) * stage;
         st.cslot = (st.rA + 64 * SL_CR) % SL_CR;
-        const bool passA = 2 * stage >= T, passB = 2 * stage + 1 >= T;    // fewer than NL sweeps asked: copy rows through
+        bool pass[K], all_pass = true;                                    // fewer than NL sweeps asked: copy rows through
+#pragma unroll
+        for (int j = 0; j < K; ++j) { pass[j] = K * stage + j >= T; all_pass = all_pass && pass[j]; }
         const bool store_lane = l >= SL_NL / 4 && l < LN - SL_NL / 4 && (x0 + 4 * l) < W;
         const int lane_off = x0 + 4 * l;
         const int lane_safe = min(max(lane_off, 0), W - 4);
         // the wavefront that holds the last stage (it alone touches the destination)
         const bool lastw = __builtin_amdgcn_readfirstlane(tid / 64) == (SL_NS * LN - 1) / 64;
         // Steps at which this wavefront's stages have nothing to contribute.  Sweep k of a chunk is needed on rows
-        // ya - (NL - k) .. yb - 1 + (NL - k) only; stage s makes row rA = rho0 - 2 - 3 s + t of sweep 2 s + 1 and row rA - 1 of
-        // sweep 2 s + 2 at step t, so it is needed for 5 s + 3 <= t <= (yb - ya) + 2 NL + s.  Outside that window (the
+        // ya - (NL - k) .. yb - 1 + (NL - k) only; stage s makes row rA - j = rho0 - 2 - (K + 1) s - j + t of sweep K s + j + 1 at
+        // step t, so it is needed for (2 K + 1) s + 3 <= t <= (yb - ya) + 2 NL + s.  Outside that window (the
         // pipeline's fill and drain) the wavefront skips the arithmetic and leaves the issue slots to the other
         // workgroups of the CU; what it hands on then is never used.
         const int wv = __builtin_amdgcn_readfirstlane(tid / 64);
-        const int w_lo = 5 * ((wv * 64) / LN) + 3, w_hi = (yb - ya) + 2 * SL_NL + (wv * 64 + 63) / LN;
+        const int w_lo = (2 * K + 1) * ((wv * 64) / LN) + 3, w_hi = (yb - ya) + 2 * SL_NL + (wv * 64 + 63) / LN;
         // six steps per round (NS is a multiple): the row registers rotate by renaming instead of moves
 #define SL_STEP(U_, LASTW_)                                                                                           \
     {                                                                                                                 \
         const int ro = rho0 - SL_LAG + t + (U_);          /* row the last stage finishes at this step */              \
         const long long ra = (long long)min(max(ro + 3, ya), yb - 1) * W;      /* row whose old values are fetched */  \
         const bool idle = t + (U_) < w_lo || t + (U_) > w_hi;                                                         \
-        sl_stage_step<NL, LN, FULL, ACC, LASTW_>(st, ring, coef, stage, l, passA, passB, store_lane, lane_off, Uo + (long long)ro * W, \
+        sl_stage_step<NL, LN, K, FULL, ACC, LASTW_>(st, ring, coef, stage, l, pass, all_pass, store_lane, lane_off, Uo + (long long)ro * W, \
                                      Vo + (long long)ro * W, ro >= ya && ro < yb, Uo + ra, Vo + ra, lane_safe, idle, w12); \
         __syncthreads();                                                                                              \
     }
@@ -444,9 +464,9 @@ int ofri_hs_scaled_coefs(ofri_ctx *ctx, const float *fx, const float *fy, const 
     OFRI_LAUNCH_CHECK();
     return OFRI_OK;
 }
-template <int NL, int LN>
+template <int NL, int LN, int K = 2>
 static void sl_launch(ofri_ctx *ctx, const SlPlanes &in, float *uo, float *vo, int H, int W, int T, int zero_in, bool acc) {
-    using Cfg = SlCfg<NL, LN>;
+    using Cfg = SlCfg<NL, LN, K>;
     const int tiles_x = ceil_div(W, Cfg::OX);
     // As many row chunks as fill the chip once with the workgroups per CU that the LDS allows.  Every chunk pays
     // NL + LAG rows of fill, so the last workgroup per CU is used only where the chunks stay long (4096 x 4096:
@@ -463,19 +483,19 @@ static void sl_launch(ofri_ctx *ctx, const SlPlanes &in, float *uo, float *vo, i
     // and 58 -> 52 us per launch), 6 for the deeper one (232 -> 232 and 76 -> 69 us)
     const OfriPrio pr{ncu, per_cu > 1 ? 4 : 0, NL == SL_NL_MAIN ? 8 : 6};
     if (T == NL) {
-        if (acc) k_hs_stream<NL, true, true, LN><<<grid, thr, 0, ctx->stream>>>(in, uo, vo, H, W, T, tiles_x, chunk_rows, zero_in, pr);
-        else k_hs_stream<NL, true, false, LN><<<grid, thr, 0, ctx->stream>>>(in, uo, vo, H, W, T, tiles_x, chunk_rows, zero_in, pr);
+        if (acc) k_hs_stream<NL, true, true, LN, K><<<grid, thr, 0, ctx->stream>>>(in, uo, vo, H, W, T, tiles_x, chunk_rows, zero_in, pr);
+        else k_hs_stream<NL, true, false, LN, K><<<grid, thr, 0, ctx->stream>>>(in, uo, vo, H, W, T, tiles_x, chunk_rows, zero_in, pr);
     } else {
-        if (acc) k_hs_stream<NL, false, true, LN><<<grid, thr, 0, ctx->stream>>>(in, uo, vo, H, W, T, tiles_x, chunk_rows, zero_in, pr);
-        else k_hs_stream<NL, false, false, LN><<<grid, thr, 0, ctx->stream>>>(in, uo, vo, H, W, T, tiles_x, chunk_rows, zero_in, pr);
+        if (acc) k_hs_stream<NL, false, true, LN, K><<<grid, thr, 0, ctx->stream>>>(in, uo, vo, H, W, T, tiles_x, chunk_rows, zero_in, pr);
+        else k_hs_stream<NL, false, false, LN, K><<<grid, thr, 0, ctx->stream>>>(in, uo, vo, H, W, T, tiles_x, chunk_rows, zero_in, pr);
     }
 }
 // strips of 256 columns where two workgroups per CU still get long row chunks
 static bool sl_wide_pays(ofri_ctx *ctx, int H, int W) {
     if (ctx->hs_fuse == 32) return true;                    // asked for (ofri_hs_set_fuse)
     if (ctx->hs_fuse == 16) return false;
-    const int tiles_x = ceil_div(W, SlCfg<SL_NL_MAIN, 64>::OX);
-    const int nchunks = max(1, SlCfg<SL_NL_MAIN, 64>::PER_CU * ofri_ctx_ncu(ctx) / tiles_x);
+    const int tiles_x = ceil_div(W, SlCfg<SL_NL_MAIN, 64, SL_K_MAIN>::OX);
+    const int nchunks = max(1, SlCfg<SL_NL_MAIN, 64, SL_K_MAIN>::PER_CU * ofri_ctx_ncu(ctx) / tiles_x);
     return ceil_div(H, nchunks) >= 128;
 }
 
@@ -503,8 +523,8 @@ int ofri_sl_sweeps(ofri_ctx *ctx, OfriSlSet &s, int n, bool to_dense, bool accum
         // CU) where the 12-sweep launches take them too: 16 sweeps at 4096 x 4096 in 180 us against 225 us in narrow strips
         if (deep && sl_wide_pays(ctx, H, W)) sl_launch<SL_NL_DEEP, 64>(ctx, in, uo, vo, H, W, T, s.zero_in, dense && accumulate);
         else if (deep) sl_launch<SL_NL_DEEP, 32>(ctx, in, uo, vo, H, W, T, s.zero_in, dense && accumulate);
-        else if (sl_wide_pays(ctx, H, W)) sl_launch<SL_NL_MAIN, 64>(ctx, in, uo, vo, H, W, T, s.zero_in, dense && accumulate);
-        else sl_launch<SL_NL_MAIN, 32>(ctx, in, uo, vo, H, W, T, s.zero_in, dense && accumulate);
+        else if (sl_wide_pays(ctx, H, W)) sl_launch<SL_NL_MAIN, 64, SL_K_MAIN>(ctx, in, uo, vo, H, W, T, s.zero_in, dense && accumulate);
+        else sl_launch<SL_NL_MAIN, 32, SL_K_MAIN>(ctx, in, uo, vo, H, W, T, s.zero_in, dense && accumulate);
         OFRI_LAUNCH_CHECK();
         s.zero_in = 0;
         if (!dense) c ^= 1;
