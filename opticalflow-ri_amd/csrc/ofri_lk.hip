@@ -191,32 +191,40 @@ k_lk_list(const float *__restrict__ I, const float *__restrict__ J, const float 
     }
 }
 
-// ---- tile of pixels (fast mode, 27 x 27 window) -------------------------------------------------------------------
+// ---- tile of pixels (fast mode; windows of 13, 27 and 31 samples, with or without the asymmetry flags) ------------------
 // A 256-thread workgroup owns 32 x 16 pixels, a lane two vertically adjacent ones.  What neighbouring pixels share is
-// made once per tile in LDS: the first image around the tile (58 x 42 window samples: a pixel's sample (oy, ox) is the
-// image at pixel - 13 + (oy, ox), edge clamped), its Scharr gradients, and the second image around the tile displaced
-// by the tile's central displacement, with a margin of LKT_R pixels for the other pixels' displacements and the Newton
-// steps (edge clamped as well, so the sampler's clamp-to-edge needs no test in the loop).  A lane then walks its pixels'
-// 729 window samples serially - no reduction across lanes: sums A11, A12, A22 first, then up to `iters` Newton steps,
-// each b = sum over the window of (J(sample + displacement) - I(sample)) * (Dx, Dy).  All samples of a pixel share one
-// pair of bilinear weights (the displacement's fractions), so J is interpolated separably: along x as the row is read
-// (each texel is read once per row), along y against the row before, kept in 27 registers per pixel.  The two pixels of
-// a lane share every read of I, Dx, Dy (pixel 1's sample row oy is pixel 0's row oy + 1).  A pixel whose displaced
-// window leaves the staged neighbourhood is put on a list and done afterwards by k_lk_list from its input
-// displacement.  Sums run in another order than the reference's lane tree and the interpolation is factored, so
-// results agree with the exact kernel to rounding (about 1e-5 px), not bit for bit.
+// made once per tile in LDS: the first image around the tile (for the 27 x 27 window 58 x 42 window samples: a pixel's
+// sample (oy, ox) is the image at pixel - half window + (oy, ox), edge clamped), its Scharr gradients, and the second image
+// around the tile displaced by the tile's central displacement, with a margin of LKT_R pixels for the other pixels'
+// displacements and the Newton steps (edge clamped as well, so the sampler's clamp-to-edge needs no test in the loop).  A
+// lane then walks its pixels' window samples serially - no reduction across lanes: sums A11, A12, A22 first, then up to
+// `iters` Newton steps, each b = sum over the window of (J(sample + displacement) - I(sample)) * (Dx, Dy).  All samples of a
+// pixel share one pair of bilinear weights (the displacement's fractions), so J is interpolated separably: along x as the
+// row is read (each texel is read once per row), along y against the row before, kept in WIN registers per pixel.  The two
+// pixels of a lane share every read of I, Dx, Dy (pixel 1's sample row oy is pixel 0's row oy + 1).  A pixel whose displaced
+// window leaves the staged neighbourhood is put on a list and done afterwards by k_lk_list from its input displacement.
+// Sums run in another order than the reference's lane tree and the interpolation is factored, so results agree with the
+// exact kernel to rounding (about 1e-5 px), not bit for bit.
+// ASYM: the vorticity-adaptive windows (src/pyrlkDenseLargeW.cl:339-374).  The reference's per-lane weights are 0 or 1 and
+// amount to: sample column 8 counts 1 - asym_left, the last column 1 - asym_right, likewise rows 8 and the last with
+// asym_top / asym_bottom (its "xid == 0" test picks the lane that owns column 8, not column 0).  A weight w multiplies the
+// gradients and the difference, so a sample counts w * w = w times.
 #define LKT_PX 32
 #define LKT_PY 16
-#define LKT_WIN 27
-#define LKT_HW 13
 #define LKT_R 6
-#define LKT_SW (LKT_PX + LKT_WIN - 1)            // 58 sample columns
-#define LKT_SH (LKT_PY + LKT_WIN - 1)            // 42 sample rows
-#define LKT_SP 60                                // their row pitch
-#define LKT_JW (LKT_SW + 1 + 2 * LKT_R)          // 71 columns of the second image
-#define LKT_JH (LKT_SH + 1 + 2 * LKT_R)          // 55 rows
-#define LKT_JP 73                                // their row pitch
-static_assert((LKT_SH + 2) * (LKT_SW + 2) <= LKT_JH * LKT_JP, "the first image with its gradient apron is staged where the second image goes later");
+template <int WIN> struct LktCfg {
+    static constexpr int HW = (WIN - 1) / 2;
+    static constexpr int SW = LKT_PX + WIN - 1;          // sample columns (27: 58)
+    static constexpr int SH = LKT_PY + WIN - 1;          // sample rows (27: 42)
+    static constexpr int SP = SW + 2;                    // their row pitch
+    static constexpr int JW = SW + 1 + 2 * LKT_R;        // columns of the second image (27: 71)
+    static constexpr int JH = SH + 1 + 2 * LKT_R;        // rows (27: 55)
+    static constexpr int JP = JW + 2;                    // their row pitch
+    static constexpr int LDS = (3 * SH * SP + JH * JP) * 4;
+    static_assert((SH + 2) * (SW + 2) <= JH * JP, "the first image with its gradient apron is staged where the second image goes later");
+    static_assert(3 * LDS + 3 * 64 <= 160 * 1024, "three workgroups per CU");
+};
+#define LKT_HW 13                                       // the default window's half width
 
 __device__ __forceinline__ int lk_to_int(float f) { return (int)fminf(fmaxf(f, -1.0e9f), 1.0e9f); }
 
@@ -225,32 +233,39 @@ struct LktPix {                  // Newton state of one pixel
     int joff;                    // offset of the window's first texel in the staged second image; < 0: not iterating
     bool live;                   // still iterating
 };
+struct LktAsym { float wl, wr, wt, wb; };        // weights of sample column 8, the last column, row 8, the last row
 
+template <int WIN, bool ASYM>
 __global__ void __launch_bounds__(256, 3)
 k_lk_tile(const float *__restrict__ I, const float *__restrict__ J, const float *__restrict__ Uin, const float *__restrict__ Vin,
           float *__restrict__ Uout, float *__restrict__ Vout, int H, int W, int iters, int tiles_x, unsigned *__restrict__ list,
-          unsigned *__restrict__ count) {
-    __shared__ float sI[LKT_SH][LKT_SP], sDx[LKT_SH][LKT_SP], sDy[LKT_SH][LKT_SP];
-    __shared__ float sJ[LKT_JH * LKT_JP];
+          unsigned *__restrict__ count, LktAsym as) {
+    using C = LktCfg<WIN>;
+    constexpr int HW = C::HW, SW = C::SW, SH = C::SH, SP = C::SP, JW = C::JW, JH = C::JH, JP = C::JP;
+    __shared__ float sI[SH][SP], sDx[SH][SP], sDy[SH][SP];
+    __shared__ float sJ[JH * JP];
     __shared__ int centre[2];
     const int tid = threadIdx.x;
     const int tx0 = (blockIdx.x % tiles_x) * LKT_PX, ty0 = (blockIdx.x / tiles_x) * LKT_PY;
+    // weight of a sample column (compile-time index) / row
+    auto wcol = [&](int ox) { return ox == 8 ? as.wl : (ox == WIN - 1 ? as.wr : 1.0f); };
+    auto wrow = [&](int oy) { return oy == 8 ? as.wt : (oy == WIN - 1 ? as.wb : 1.0f); };
     // ---- first image with a one-pixel apron (in sJ's space), then gradients
     {
-        float (*tI)[LKT_SW + 2] = reinterpret_cast<float (*)[LKT_SW + 2]>(sJ);
+        float (*tI)[SW + 2] = reinterpret_cast<float (*)[SW + 2]>(sJ);
         // a thread's loads are issued together (one per loop round would cost a memory latency each)
-        constexpr int NI = ((LKT_SH + 2) * (LKT_SW + 2) + 255) / 256;
+        constexpr int NI = ((SH + 2) * (SW + 2) + 255) / 256;
         float pre[NI];
 #pragma unroll
         for (int e = 0; e < NI; ++e) {
-            const int t = min(tid + 256 * e, (LKT_SH + 2) * (LKT_SW + 2) - 1), ly = t / (LKT_SW + 2), lx = t - ly * (LKT_SW + 2);
-            const int yy = clampi(ty0 - LKT_HW - 1 + ly, 0, H - 1), xx = clampi(tx0 - LKT_HW - 1 + lx, 0, W - 1);
+            const int t = min(tid + 256 * e, (SH + 2) * (SW + 2) - 1), ly = t / (SW + 2), lx = t - ly * (SW + 2);
+            const int yy = clampi(ty0 - HW - 1 + ly, 0, H - 1), xx = clampi(tx0 - HW - 1 + lx, 0, W - 1);
             pre[e] = I[(size_t)yy * W + xx];
         }
 #pragma unroll
         for (int e = 0; e < NI; ++e) {
             const int t = tid + 256 * e;
-            if (t < (LKT_SH + 2) * (LKT_SW + 2)) sJ[t] = pre[e];           // tI[ly][lx] is sJ[t]
+            if (t < (SH + 2) * (SW + 2)) sJ[t] = pre[e];           // tI[ly][lx] is sJ[t]
         }
         if (tid == 0) {         // the tile's central pixel (clamped into the image) gives the neighbourhood's displacement
             const size_t c = (size_t)min(ty0 + LKT_PY / 2, H - 1) * W + min(tx0 + LKT_PX / 2, W - 1);
@@ -258,8 +273,8 @@ k_lk_tile(const float *__restrict__ I, const float *__restrict__ J, const float 
             centre[1] = clampi(lk_to_int(floorf(Vin[c])), -(1 << 24), 1 << 24);
         }
         __syncthreads();
-        for (int t = tid; t < LKT_SH * LKT_SW; t += 256) {
-            const int sy = t / LKT_SW, sx = t - sy * LKT_SW;
+        for (int t = tid; t < SH * SW; t += 256) {
+            const int sy = t / SW, sx = t - sy * SW;
 #define TV(dy, dx) tI[sy + 1 + (dy)][sx + 1 + (dx)]
             const float gx = ((TV(-1, 1) + TV(1, 1)) - TV(-1, -1)) - TV(1, -1);
             const float gy = ((TV(1, -1) + TV(1, 1)) - TV(-1, -1)) - TV(-1, 1);
@@ -271,22 +286,22 @@ k_lk_tile(const float *__restrict__ I, const float *__restrict__ J, const float 
         __syncthreads();
     }
     // ---- second image around the displaced tile
-    const int jx0 = tx0 - LKT_HW - LKT_R + centre[0], jy0 = ty0 - LKT_HW - LKT_R + centre[1];
+    const int jx0 = tx0 - HW - LKT_R + centre[0], jy0 = ty0 - HW - LKT_R + centre[1];
     {
-        constexpr int NJ = (LKT_JH * LKT_JW + 255) / 256, NB = 8;          // in batches of eight loads
+        constexpr int NB = 8, NJ = ((JH * JW + 255) / 256 + NB - 1) / NB * NB;          // in batches of eight loads
 #pragma unroll
         for (int b0 = 0; b0 < NJ; b0 += NB) {
             float pre[NB];
 #pragma unroll
             for (int e = 0; e < NB; ++e) {
-                const int t = min(tid + 256 * (b0 + e), LKT_JH * LKT_JW - 1), ly = t / LKT_JW, lx = t - ly * LKT_JW;
+                const int t = min(tid + 256 * (b0 + e), JH * JW - 1), ly = t / JW, lx = t - ly * JW;
                 const int yy = clampi(jy0 + ly, 0, H - 1), xx = clampi(jx0 + lx, 0, W - 1);
                 pre[e] = J[(size_t)yy * W + xx];
             }
 #pragma unroll
             for (int e = 0; e < NB; ++e) {
-                const int t = tid + 256 * (b0 + e), ly = t / LKT_JW, lx = t - ly * LKT_JW;
-                if (t < LKT_JH * LKT_JW) sJ[ly * LKT_JP + lx] = pre[e];
+                const int t = tid + 256 * (b0 + e), ly = t / JW, lx = t - ly * JW;
+                if (t < JH * JW) sJ[ly * JP + lx] = pre[e];
             }
         }
     }
@@ -300,16 +315,24 @@ k_lk_tile(const float *__restrict__ I, const float *__restrict__ J, const float 
     LktPix q[2];
     q[0].A11 = q[0].A12 = q[0].A22 = q[1].A11 = q[1].A12 = q[1].A22 = 0.f;
 #pragma unroll 1
-    for (int sy = 0; sy <= LKT_WIN; ++sy) {
-        const bool use0 = sy < LKT_WIN, use1 = sy > 0;      // uniform
+    for (int sy = 0; sy <= WIN; ++sy) {
+        const bool use0 = sy < WIN, use1 = sy > 0;      // uniform
+        const float wy0 = ASYM ? wrow(sy) : 1.0f, wy1 = ASYM ? wrow(sy - 1) : 1.0f;
 #pragma unroll
-        for (int ox = 0; ox < LKT_WIN; ++ox) {
-            const float dx = pDx[sy * LKT_SP + ox], dy = pDy[sy * LKT_SP + ox];
-            if (use0) { q[0].A11 = fmaf(dx, dx, q[0].A11); q[0].A12 = fmaf(dx, dy, q[0].A12); q[0].A22 = fmaf(dy, dy, q[0].A22); }
-            if (use1) { q[1].A11 = fmaf(dx, dx, q[1].A11); q[1].A12 = fmaf(dx, dy, q[1].A12); q[1].A22 = fmaf(dy, dy, q[1].A22); }
+        for (int ox = 0; ox < WIN; ++ox) {
+            float dx = pDx[sy * SP + ox], dy = pDy[sy * SP + ox];
+            if (ASYM && (ox == 8 || ox == WIN - 1)) { dx *= wcol(ox); dy *= wcol(ox); }
+            if (ASYM) {
+                const float dx0 = dx * wy0, dy0 = dy * wy0, dx1 = dx * wy1, dy1 = dy * wy1;
+                if (use0) { q[0].A11 = fmaf(dx0, dx0, q[0].A11); q[0].A12 = fmaf(dx0, dy0, q[0].A12); q[0].A22 = fmaf(dy0, dy0, q[0].A22); }
+                if (use1) { q[1].A11 = fmaf(dx1, dx1, q[1].A11); q[1].A12 = fmaf(dx1, dy1, q[1].A12); q[1].A22 = fmaf(dy1, dy1, q[1].A22); }
+            } else {
+                if (use0) { q[0].A11 = fmaf(dx, dx, q[0].A11); q[0].A12 = fmaf(dx, dy, q[0].A12); q[0].A22 = fmaf(dy, dy, q[0].A22); }
+                if (use1) { q[1].A11 = fmaf(dx, dx, q[1].A11); q[1].A12 = fmaf(dx, dy, q[1].A12); q[1].A22 = fmaf(dy, dy, q[1].A22); }
+            }
         }
     }
-    const float hw = (float)LKT_HW;
+    const float hw = (float)HW;
     float u0[2], v0[2];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
@@ -333,65 +356,69 @@ k_lk_tile(const float *__restrict__ I, const float *__restrict__ J, const float 
             const float fx = floorf(q[k].ppx), fy = floorf(q[k].ppy);
             q[k].ax = q[k].ppx - fx; q[k].ay = q[k].ppy - fy;
             const int rx = lk_to_int(fx) - jx0, ry = lk_to_int(fy) - jy0;
-            if (rx < 0 || ry < 0 || rx + LKT_WIN >= LKT_JW || ry + LKT_WIN >= LKT_JH) {        // outside the neighbourhood: deferred
+            if (rx < 0 || ry < 0 || rx + WIN >= JW || ry + WIN >= JH) {        // outside the neighbourhood: deferred
                 q[k].live = false; finished[k] = false;
                 list[atomicAdd(count, 1u)] = (unsigned)((size_t)(gy + k) * W + gx);
                 continue;
             }
-            q[k].joff = ry * LKT_JP + rx;
+            q[k].joff = ry * JP + rx;
             q[k].b1 = q[k].b2 = 0.f;
         }
         if (__builtin_amdgcn_ballot_w64(q[0].live || q[1].live) == 0) break;
         // lanes with nothing to do walk a harmless window (offset 0) and drop the result
         const float *j0p = sJ + (q[0].live ? q[0].joff : 0), *j1p = sJ + (q[1].live ? q[1].joff : 0);
         const float ax0 = q[0].ax, ay0 = q[0].ay, ax1 = q[1].ax, ay1 = q[1].ay;
-        float h0[LKT_WIN], h1[LKT_WIN], b10 = 0.f, b20 = 0.f, b11 = 0.f, b21 = 0.f;
+        float h0[WIN], h1[WIN], b10 = 0.f, b20 = 0.f, b11 = 0.f, b21 = 0.f;
         {   // row 0 of both windows, interpolated along x
             float a = j0p[0], b = j1p[0];
 #pragma unroll
-            for (int ox = 0; ox < LKT_WIN; ++ox) {
+            for (int ox = 0; ox < WIN; ++ox) {
                 const float an = j0p[ox + 1], bn = j1p[ox + 1];
                 h0[ox] = fmaf(ax0, an - a, a); h1[ox] = fmaf(ax1, bn - b, b);
                 a = an; b = bn;
             }
         }
-        // pixel 0 takes sample rows 0..26 of the lane, pixel 1 rows 1..27; both advance one row of J per round
-#define LKT_TAP(K, HP, JP, AX, AY, B1, B2, JOLD)                                                 \
+        // pixel 0 takes sample rows 0..WIN-1 of the lane, pixel 1 rows 1..WIN; both advance one row of J per round
+#define LKT_TAP(HP, JP_, AX, AY, B1, B2, JOLD, WR)                                               \
         {                                                                                        \
-            const float jn = JP[ox + 1];                                                         \
+            const float jn = JP_[ox + 1];                                                        \
             const float h = fmaf(AX, jn - JOLD, JOLD);                                           \
             const float ji = fmaf(AY, h - HP[ox], HP[ox]);                                       \
-            const float df = ji - vi;                                                            \
+            float df = ji - vi;                                                                  \
+            if (ASYM) df *= (ox == 8 || ox == WIN - 1) ? WR * wcol(ox) : WR;                     \
             B1 = fmaf(df, dx, B1); B2 = fmaf(df, dy, B2);                                        \
             HP[ox] = h; JOLD = jn;                                                               \
         }
         {   // sample row 0: pixel 0 only
-            j0p += LKT_JP;
+            j0p += JP;
             float a = j0p[0];
+            const float w0 = ASYM ? wrow(0) : 1.0f;
 #pragma unroll
-            for (int ox = 0; ox < LKT_WIN; ++ox) {
+            for (int ox = 0; ox < WIN; ++ox) {
                 const float vi = pI[ox], dx = pDx[ox], dy = pDy[ox];
-                LKT_TAP(0, h0, j0p, ax0, ay0, b10, b20, a)
+                LKT_TAP(h0, j0p, ax0, ay0, b10, b20, a, w0)
             }
         }
 #pragma unroll 1
-        for (int sy = 1; sy < LKT_WIN; ++sy) {
-            j0p += LKT_JP; j1p += LKT_JP;
+        for (int sy = 1; sy < WIN; ++sy) {
+            j0p += JP; j1p += JP;
             float a = j0p[0], b = j1p[0];
+            const float w0 = ASYM ? wrow(sy) : 1.0f, w1 = ASYM ? wrow(sy - 1) : 1.0f;
 #pragma unroll
-            for (int ox = 0; ox < LKT_WIN; ++ox) {
-                const float vi = pI[sy * LKT_SP + ox], dx = pDx[sy * LKT_SP + ox], dy = pDy[sy * LKT_SP + ox];
-                LKT_TAP(0, h0, j0p, ax0, ay0, b10, b20, a)
-                LKT_TAP(1, h1, j1p, ax1, ay1, b11, b21, b)
+            for (int ox = 0; ox < WIN; ++ox) {
+                const float vi = pI[sy * SP + ox], dx = pDx[sy * SP + ox], dy = pDy[sy * SP + ox];
+                LKT_TAP(h0, j0p, ax0, ay0, b10, b20, a, w0)
+                LKT_TAP(h1, j1p, ax1, ay1, b11, b21, b, w1)
             }
         }
-        {   // sample row 27: pixel 1 only
-            j1p += LKT_JP;
+        {   // sample row WIN: pixel 1 only
+            j1p += JP;
             float b = j1p[0];
+            const float w1 = ASYM ? wrow(WIN - 1) : 1.0f;
 #pragma unroll
-            for (int ox = 0; ox < LKT_WIN; ++ox) {
-                const float vi = pI[LKT_WIN * LKT_SP + ox], dx = pDx[LKT_WIN * LKT_SP + ox], dy = pDy[LKT_WIN * LKT_SP + ox];
-                LKT_TAP(1, h1, j1p, ax1, ay1, b11, b21, b)
+            for (int ox = 0; ox < WIN; ++ox) {
+                const float vi = pI[WIN * SP + ox], dx = pDx[WIN * SP + ox], dy = pDy[WIN * SP + ox];
+                LKT_TAP(h1, j1p, ax1, ay1, b11, b21, b, w1)
             }
         }
 #undef LKT_TAP
@@ -414,6 +441,14 @@ k_lk_tile(const float *__restrict__ I, const float *__restrict__ J, const float 
         }
 }
 
+template <int WIN>
+static void lkt_launch(ofri_ctx *ctx, const float *im1, const float *im2, const float *U_in, const float *V_in, float *U_out, float *V_out,
+                       int rows, int cols, int niter, unsigned *list, unsigned *count, bool asym, const LktAsym &as) {
+    const int tiles_x = ceil_div(cols, LKT_PX), tiles = tiles_x * ceil_div(rows, LKT_PY);
+    if (asym) k_lk_tile<WIN, true><<<tiles, 256, 0, ctx->stream>>>(im1, im2, U_in, V_in, U_out, V_out, rows, cols, niter, tiles_x, list, count, as);
+    else k_lk_tile<WIN, false><<<tiles, 256, 0, ctx->stream>>>(im1, im2, U_in, V_in, U_out, V_out, rows, cols, niter, tiles_x, list, count, as);
+}
+
 extern "C" int ofri_lk_set_mode(ofri_ctx *ctx, int mode) {
     OFRI_REQUIRE(ctx, "null context");
     OFRI_REQUIRE(mode == 0 || mode == -1, "mode: 0 fast (tile of pixels where the window allows), -1 exact (one wavefront per pixel)");
@@ -434,7 +469,9 @@ extern "C" int ofri_lk_compute(ofri_ctx *ctx, const float *im1, const float *im2
     p.half_x = p.half_y = (p.win_x - 1) >> 1;
     p.asym_l = asym_left; p.asym_r = asym_right; p.asym_t = asym_top; p.asym_b = asym_bottom;
     p.iters = niter;
-    const bool tile_ok = ctx->lk_mode == 0 && half_window == LKT_HW && !(asym_left | asym_right | asym_top | asym_bottom) &&
+    // the tile kernel is built for the windows of 13, 27 (the reference's default) and 31 samples; the flags are 0 or 1
+    const bool flags01 = ((asym_left | asym_right | asym_top | asym_bottom) & ~1) == 0;
+    const bool tile_ok = ctx->lk_mode == 0 && (half_window == 6 || half_window == LKT_HW || half_window == 15) && flags01 &&
                          U_out != U_in && V_out != V_in && U_out != V_in && V_out != U_in;
     if (tile_ok) {
         // fast mode: tiles of pixels; the pixels it defers (displaced window outside the staged neighbourhood) follow
@@ -443,8 +480,11 @@ extern "C" int ofri_lk_compute(ofri_ctx *ctx, const float *im1, const float *im2
         OFRI_TRY(lst.get((n + 1) * sizeof(unsigned)));
         unsigned *count = lst.as<unsigned>(), *list = count + 1;
         OFRI_TRY(ofri_dev_fill(ctx, count, 0, sizeof(unsigned)));
-        const int tiles_x = ceil_div(cols, LKT_PX), tiles = tiles_x * ceil_div(rows, LKT_PY);
-        k_lk_tile<<<tiles, 256, 0, ctx->stream>>>(im1, im2, U_in, V_in, U_out, V_out, rows, cols, niter, tiles_x, list, count);
+        const bool asym = (asym_left | asym_right | asym_top | asym_bottom) != 0;
+        const LktAsym as{(float)(1 - asym_left), (float)(1 - asym_right), (float)(1 - asym_top), (float)(1 - asym_bottom)};
+        if (half_window == 6) lkt_launch<13>(ctx, im1, im2, U_in, V_in, U_out, V_out, rows, cols, niter, list, count, asym, as);
+        else if (half_window == 15) lkt_launch<31>(ctx, im1, im2, U_in, V_in, U_out, V_out, rows, cols, niter, list, count, asym, as);
+        else lkt_launch<27>(ctx, im1, im2, U_in, V_in, U_out, V_out, rows, cols, niter, list, count, asym, as);
         OFRI_LAUNCH_CHECK();
         int gl = (int)((n + LK_PX - 1) / LK_PX);
         if (gl > 512) gl = 512;              // a small resident grid: the kernel loops over *count, which is mostly zero

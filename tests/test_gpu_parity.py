@@ -874,6 +874,20 @@ def test_lk_asymmetric_windows_and_driver(ctx, pair):
         Un, Vn, _ = ad._run(ctx.upload(I0), ctx.upload(I1), ctx.upload(z), ctx.upload(z), cfg)
         Ur, Vr = lk.lk_dense(I0, I1, z, z, 5, 13, cfg)
         assert flow_rel(Un.numpy(), Vn.numpy(), Ur, Vr) < 1e-5
+    # the other windows the tile kernel is built for (13 and 31 samples), every flag set at least once, both modes
+    for hw, cfg in ((6, [1, 0, 0, 1]), (6, [0, 1, 1, 0]), (15, [1, 1, 1, 1]), (15, [0, 1, 0, 0])):
+        adw = denseLucasKanade_PyCl(halfWindow=hw, Niter=4, enableVorticityEnhancement=True)
+        Ur, Vr = lk.lk_dense(I0, I1, z, z, 4, hw, cfg)
+        for mode in (0, -1):
+            ctx.set_lk_mode(mode)
+            try:
+                Un, Vn, _ = adw._run(ctx.upload(I0), ctx.upload(I1), ctx.upload(z), ctx.upload(z), cfg)
+            finally:
+                ctx.set_lk_mode(0)
+            r = flow_rel(Un.numpy(), Vn.numpy(), Ur, Vr)
+            print("lk window", 2 * hw + 1, "flags", cfg, "mode", mode, "rel L2 vs oracle", r)
+            assert r < (1e-5 if mode == -1 else 1e-4)
+            assert float(np.abs(Un.numpy() - Ur).max()) < 2e-3 and float(np.abs(Vn.numpy() - Vr).max()) < 2e-3
     # through the pyramid driver with the adapter's defaults (no warping, final level not rescaled)
     J0, J1 = pair[0][128:256, 128:256].copy(), pair[1][128:256, 128:256].copy()
     U, V = flow(J0, J1, 2.0, denseLucasKanade_PyCl(), 2, 1, None)
