@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Turn one GPU-box collection (gpurun_out/<dir>, made by tools/collect_profiles.sh) into the files under profiles/.
 
-Usage: python tools/make_profiles.py gpurun_out/<dir> [tag]      (tag defaults to r02)
+Usage: python tools/make_profiles.py gpurun_out/<dir> [tag]      (tag defaults to r03)
 Writes  <tag>_bench_kernel_stats.csv / _by_grid.csv      rocprofv3 --kernel-trace --stats of `python bench.py`
         <tag>_paths_kernel_stats.csv                     the same of `python bench_paths.py`
         <tag>_pmc_hbm_traffic.md, pmc_traffic.json       FETCH_SIZE / WRITE_SIZE passes (gfx950: reads doubled)
@@ -16,7 +16,7 @@ import shutil
 import sys
 
 src = sys.argv[1]
-tag = sys.argv[2] if len(sys.argv) > 2 else "r02"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r03"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 dst = os.path.join(root, "profiles")
 CLOCK_GHZ = 2.4           # peak engine clock: SIMD utilisations below are lower bounds when the chip runs slower
