@@ -67,6 +67,44 @@ k_level_coefs(const float *__restrict__ first, const float *__restrict__ second,
         }
     }
     __syncthreads();
+    // Tiles whose margins lie inside the image (all but the outermost ring) need no border rule and no bounds test: the
+    // taps are neighbours in the tile.  Same operations in the same order as the general path below.
+    const bool inner = ox >= 0 && oy >= 0 && ox + WC <= W && oy + WR <= H && tx0 + LV_TX + 1 < W && ty0 + LV_TY + 1 < H;
+    if (inner) {
+        for (int idx = tid; idx < WR * FC; idx += 256) {
+            const int r = idx / FC, c = idx - r * FC;
+            float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                a0 = __fadd_rn(a0, __fmul_rn(tw[0][r][c + 2 * h - j], taps.k[j]));
+                a1 = __fadd_rn(a1, __fmul_rn(tw[1][r][c + 2 * h - j], taps.k[j]));
+            }
+            rf[0][r][c] = a0; rf[1][r][c] = a1;
+        }
+        __syncthreads();
+        for (int idx = tid; idx < FR * FC; idx += 256) {
+            const int r = idx / FC, c = idx - r * FC;
+            float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                a0 = __fadd_rn(a0, __fmul_rn(rf[0][r + 2 * h - j][c], taps.k[j]));
+                a1 = __fadd_rn(a1, __fmul_rn(rf[1][r + 2 * h - j][c], taps.k[j]));
+            }
+            ff[0][r][c] = a0; ff[1][r][c] = a1;
+        }
+        __syncthreads();
+        // a thread's pixels: column tid % 64, rows tid / 64 + 4 k; the lower row of one pixel's window is the upper row of the next but four
+#pragma unroll
+        for (int k = 0; k < LV_TY / 4; ++k) {
+            const int r = (tid >> 6) + 4 * k, c = tid & 63, r0 = r + 1, c0 = c + 1;
+            float gx, gy, gt;
+            hs_derivs_of(ff[0][r0][c0], ff[0][r0][c0 + 1], ff[0][r0 + 1][c0], ff[0][r0 + 1][c0 + 1], ff[1][r0][c0], ff[1][r0][c0 + 1],
+                         ff[1][r0 + 1][c0], ff[1][r0 + 1][c0 + 1], gx, gy, gt);
+            const size_t s = (size_t)(ty0 + r) * W + tx0 + c;
+            hs_scaled(gx, gy, gt, a2, o.fx[s], o.fy[s], o.ft[s]);
+        }
+        return;
+    }
     for (int idx = tid; idx < WR * FC; idx += 256) {
         const int r = idx / FC, c = idx - r * FC, y = oy + r, x = tx0 - 1 + c;
         if (y < 0 || y >= H || x < 0 || x >= W) continue;
