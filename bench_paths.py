@@ -68,7 +68,14 @@ def main():
         k0, k1 = ctx.upload(g0.astype(np.float32)), ctx.upload(g1.astype(np.float32))
         ms = timed(lambda: pyramidal_flow_device(k0, k1, 0.0, Farneback_PyCL(), 2, 1, None), a.reps)
         report("cfg3_farneback_2_level_pyramid", m, ms)
-        del k0, k1
+        # the same pair replayed from a captured graph (piv_plan.FlowPlan: the path for streams of equally sized pairs)
+        from piv_plan import FlowPlan
+        plan = FlowPlan((m, m), 0.0, lambda: Farneback_PyCL(), pyramidalLevels=2, ctx=ctx)
+        plan.load(k0, k1)
+        ms = timed(plan.run, a.reps)
+        report("cfg3_farneback_2_level_pyramid_captured_graph", m, ms)
+        plan.close()
+        del k0, k1, plan
     ms = timed(lambda: pyramidal_flow_device(im0, im1, 0.0, Farneback_PyCL(), 2, 1, 0.48, LiuShenOpticalFlowAlgoAdapter(10)), a.reps)
     report("cfg4_farneback_plus_liushen_2_level", n, ms)
     ms = timed(lambda: pyramidal_flow_device(im0, im1, 3.4, HSOpticalFlowAlgoAdapter([21, 45], 100), 2, 1, 0.48,

@@ -20,6 +20,10 @@ def resize_bilinear_device(im, size_wh):
     return out
 
 
+_EXPANSION_CONSTS = {}      # (polyN, polySigma) -> FarnebackPrepareGaussian()
+_BLUR_TAPS = {}             # (n, sigma) -> float32 taps of getGaussianKernelBitExact
+
+
 class Farneback_PyCL(object):
     def __init__(self, windowSize=33, Niters=5, polyN=7, polySigma=1.5, useGaussian=True, pyrScale=0.5,
                  pyramidalLevels=1, platformID=0, deviceID=0, provideGenericPyramidalDefaults=True):
@@ -74,7 +78,10 @@ class Farneback_PyCL(object):
 
     def setPolynomialExpansionConsts(self):
         n = self.polyN
-        g, xg, xxg, a, b, c, d = self.FarnebackPrepareGaussian()
+        key = (int(self.polyN), float(self.polySigma))
+        if key not in _EXPANSION_CONSTS:            # the same tables for every call with these parameters (host work of a millisecond)
+            _EXPANSION_CONSTS[key] = self.FarnebackPrepareGaussian()
+        g, xg, xxg, a, b, c, d = _EXPANSION_CONSTS[key]
         self.matrixIGD = np.array([a, b, c, d], dtype=np.float64)
         self.matrixIG = self.matrixIGD.astype(np.float32)
         self.matrixG = g[n:].reshape([1, n + 1]).copy()
@@ -82,8 +89,11 @@ class Farneback_PyCL(object):
         self.matrixXXG = xxg[n:].reshape([1, n + 1]).copy()
 
     def getGaussianKernel(self, n, sigma):
-        _, kernel_bitexact = getGaussianKernelBitExact(n, sigma)
-        return np.float32(kernel_bitexact).reshape([1, n])
+        key = (int(n), float(sigma))
+        if key not in _BLUR_TAPS:                   # 28-digit decimal arithmetic per tap: once per (size, sigma)
+            _, kernel_bitexact = getGaussianKernelBitExact(n, sigma)
+            _BLUR_TAPS[key] = np.float32(kernel_bitexact).reshape([1, n])
+        return _BLUR_TAPS[key].copy()
 
     def setGaussianBlurKernel(self, smoothSize, sigma):
         g = self.getGaussianKernel(smoothSize, sigma)
@@ -203,15 +213,19 @@ class Farneback_PyCL(object):
             sigma = (1.0 / scale - 1.0) * 0.5
             smoothSize = max(int(round(sigma * 5)) | 1, 3)
             width, height = int(round(size[1] * scale)), int(round(size[0] * scale))
-            if prevX is None:
-                curX, curY = resize_bilinear_device(U, (width, height)), resize_bilinear_device(V, (width, height))
-                mult = np.float32(scale)
+            srcX, srcY = (U, V) if prevX is None else (prevX, prevY)
+            mult = np.float32(scale) if prevX is None else np.float32(1.0 / self.pyrScale)
+            if srcX.shape == (height, width) and mult == 1.0 and self.numIters > 0:
+                # the resize is an identity copy (:531-540) and nothing scales it: the incoming flow is read where it is
+                # (only the first updateMatrices reads it) and the last iteration's updateFlow writes fresh arrays
+                inX, inY = srcX, srcY
+                curX, curY = ctx.empty((height, width)), ctx.empty((height, width))
             else:
-                curX, curY = resize_bilinear_device(prevX, (width, height)), resize_bilinear_device(prevY, (width, height))
-                mult = np.float32(1.0 / self.pyrScale)
-            if mult != 1.0:
-                _ofri.check(lib.ofri_scale_inplace(ctx.handle, curX.ptr, float(mult), curX.size))
-                _ofri.check(lib.ofri_scale_inplace(ctx.handle, curY.ptr, float(mult), curY.size))
+                curX, curY = resize_bilinear_device(srcX, (width, height)), resize_bilinear_device(srcY, (width, height))
+                if mult != 1.0:
+                    _ofri.check(lib.ofri_scale_inplace(ctx.handle, curX.ptr, float(mult), curX.size))
+                    _ofri.check(lib.ofri_scale_inplace(ctx.handle, curY.ptr, float(mult), curY.size))
+                inX, inY = curX, curY
             self.setGaussianBlurKernel(smoothSize, sigma)
             ksh = int(smoothSize / 2)                        # the reference passes smoothSize/2 through cl.cltypes.int
             if (height, width) == tuple(size):               # the resize between blur and expansion (:570-585) is an identity
@@ -220,7 +234,7 @@ class Farneback_PyCL(object):
                 RA = self._polyexp(resize_bilinear_device(self._blur(im1, ksh), (width, height)))
                 RB = self._polyexp(resize_bilinear_device(self._blur(im2, ksh), (width, height)))
             M, Mnext = ctx.empty((5 * height, width)), ctx.empty((5 * height, width))
-            self._update_matrices(curX, curY, RA, RB, M)
+            self._update_matrices(inX, inY, RA, RB, M)
             if self.useGaussianFilter:
                 self.setGaussianBlurKernel(self.windowSize, self.windowSize / 2 * 0.3)
             wksh = int(self.windowSize / 2)
