@@ -226,6 +226,11 @@ def main():
         2, 1, None, None, True, True, True, True)
     np.savez_compressed(os.path.join(OUT, "driver.npz"), **d)
 
+    # ---- the example script's own iteration count (examples/PyHSchunck_Fs3_4_PyrLvls2.py:132: Niter = 600) ----
+    d = {}
+    run("hs_L2_n600", I0.copy(), I1.copy(), 3.4, H.HSOpticalFlowAlgoAdapter([21, 45], 600), 2, 1, None)
+    np.savez_compressed(os.path.join(OUT, "driver_n600.npz"), **d)
+
     # ---- optical-flow-equation warp, biLinear=False (GenericPyramidalOpticalFlow.py:189-221) --------
     w = {}
     wi = I0[60:180, 200:350].copy()                                        # 120 x 150

@@ -41,6 +41,10 @@ def test_example_scripts_call_sequence(tmp_path, pair):
     m = scipy.io.loadmat(fn)
     np.testing.assert_array_equal(m['velocities']['u'][0, 0], U)
     assert int(np.ravel(m['parameters']['imageWidth'][0, 0])[0]) == 512
+    # the same script with its own Niter = 600 (examples/PyHSchunck_Fs3_4_PyrLvls2.py:132)
+    d6 = load_gold("driver_n600")
+    [U, V] = genericPyramidalOpticalFlow(Iold, Inew, 3.4, HSOpticalFlowAlgoAdapter([21, 45], 600), 2, 1, None)
+    assert rel_l2(np.stack([U[::2, ::2], V[::2, ::2]]), np.stack([d6["hs_L2_n600_U"], d6["hs_L2_n600_V"]])) < 1e-4
     # LiuSE_PyHSchunck_Fs3_4_PyrLvls2.py
     [U, V] = genericPyramidalOpticalFlow(Iold, Inew, 3.4, HSOpticalFlowAlgoAdapter([21, 45], 100), 2, 1, 0.48,
                                          LiuShenOpticalFlowAlgoAdapter(5))

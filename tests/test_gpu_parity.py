@@ -183,11 +183,12 @@ def test_hs_launch_shapes_agree_bitwise(ctx, shape, nit):
 
 
 
-@pytest.mark.parametrize("nit", [24, 25, 27, 28, 29, 40])
+@pytest.mark.parametrize("nit", [24, 25, 27, 28, 29, 40, 600])
 def test_hs_pipeline_tail_lengths_agree_bitwise(ctx, nit):
     """On fields large enough for the row-streaming pipeline the automatic mode splits the sweeps into launches of 12,
     a deeper last launch when 13 to 16 are left, and the tile kernel for other remainders: every split gives the bits of
-    one sweep per launch."""
+    one sweep per launch.  600: the iteration count of the reference's own scripts
+    (examples/PyHSchunck_Fs3_4_PyrLvls2.py:132), fifty launches of 12."""
     from HornSchunck import hs_iterate_device
     shape = (2048, 2052)
     rng = np.random.default_rng(nit)

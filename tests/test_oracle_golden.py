@@ -118,8 +118,8 @@ def test_liushen_adapter_swaps_components():
     assert err == pytest.approx(float(l["crop_err"]), rel=1e-6)
 
 
-def _check_driver(name, U, V):
-    d = load_gold("driver")
+def _check_driver(name, U, V, gold="driver"):
+    d = load_gold(gold)
     s = int(d[name + "_sub"])
     np.testing.assert_array_equal(U[::s, ::s], d[name + "_U"]); np.testing.assert_array_equal(V[::s, ::s], d[name + "_V"])
     assert float(U.astype(np.float64).sum()) == pytest.approx(d[name + "_Ustats"][0], rel=1e-12, abs=1e-9)
@@ -131,6 +131,13 @@ def test_driver_hs_levels(pair):
     _check_driver("hs_L1_a21", *pyramid.pyramidal_flow(I0.copy(), I1.copy(), 3.4, hs.HSAdapter([21], 100), 1, 1, None))
     _check_driver("hs_L2", *pyramid.pyramidal_flow(I0.copy(), I1.copy(), 3.4, hs.HSAdapter([21, 45], 100), 2, 1, None))
     _check_driver("hs_L3_nofilter", *pyramid.pyramidal_flow(I0.copy(), I1.copy(), 0.0, hs.HSAdapter([21, 45, 60], 30), 3, 1, None))
+
+
+def test_driver_hs_with_the_scripts_own_iteration_count(pair):
+    """Niter = 600 as in examples/PyHSchunck_Fs3_4_PyrLvls2.py:132."""
+    I0, I1 = pair
+    _check_driver("hs_L2_n600", *pyramid.pyramidal_flow(I0.copy(), I1.copy(), 3.4, hs.HSAdapter([21, 45], 600), 2, 1, None),
+                  gold="driver_n600")
 
 
 def test_driver_variants(pair):
