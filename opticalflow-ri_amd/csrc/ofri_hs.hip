@@ -533,7 +533,7 @@ extern "C" int ofri_hs_level(ofri_ctx *ctx, const float *im1, const float *im2, 
     OFRI_REQUIRE(rows > 0 && cols > 0 && niter >= 0, "bad shape or niter");
     const void *q[4] = {im1, im2, U_flow, V_flow};
     const int n_stream = hs_stream_share(ctx, q, 4, niter, rows, cols);
-    if (n_stream > 0 && ofri_sl_level_ok(ntaps)) {
+    if (n_stream > 0 && ofri_sl_level_ok(ntaps, rows, cols)) {
         const HsLevelFill lf = {warp ? U_flow : nullptr, warp ? V_flow : nullptr, taps_host, ntaps};
         // computeDerivatives takes (im2, im1) of the adapter's (im1, im2)   (HornSchunck.py:37,73,84)
         return hs_stream_path(ctx, nullptr, nullptr, U_flow, V_flow, nullptr, nullptr, nullptr, im2, im1, alpha * alpha, niter,

@@ -26,6 +26,6 @@ int ofri_sl_sweeps(ofri_ctx *ctx, OfriSlSet &s, int n, bool to_dense, bool accum
 int ofri_hs_scaled_coefs(ofri_ctx *ctx, const float *fx, const float *fy, const float *ft, const float *first,
                          const float *second, float *A, float *B, float *C, float a2, int H, int W, int pitch_out = 0);
 // the same from a pyramid level's images: warp (if U, V are given), pre-filter, derivatives in one pass
-bool ofri_sl_level_ok(int ntaps);
+bool ofri_sl_level_ok(int ntaps, int H, int W);
 int ofri_sl_fill_level(ofri_ctx *ctx, OfriSlSet &s, const float *first, const float *second, const float *U, const float *V,
                        const float *taps_host, int ntaps, float a2, int H, int W);
