@@ -286,6 +286,10 @@ int ofri_lk_set_mode(ofri_ctx *ctx, int mode);
  * float32: horizontal then vertical pass, float64 accumulation, float32 intermediate. */
 int ofri_resize_bicubic(ofri_ctx *ctx, const float *src, int rows_in, int cols_in,
                         float *dst, int rows_out, int cols_out);
+/* Both frames of a pyramid level in one launch (src/GenericPyramidalOpticalFlow.py:336-343 resizes im1 and im2 one after the
+ * other): the same numbers as two calls of ofri_resize_bicubic. */
+int ofri_resize_bicubic_pair(ofri_ctx *ctx, const float *src1, const float *src2, int rows_in, int cols_in,
+                             float *dst1, float *dst2, int rows_out, int cols_out);
 /* Pillow BILINEAR resize used by Farneback_PyCL.imresize (src/Farneback_PyCL.py:62-63) */
 int ofri_resize_bilinear(ofri_ctx *ctx, const float *src, int rows_in, int cols_in,
                          float *dst, int rows_out, int cols_out);
@@ -294,6 +298,10 @@ int ofri_resize_bilinear(ofri_ctx *ctx, const float *src, int rows_in, int cols_
  * rounded to float32 and then multiplied by post_scale in float32 (:169-172; pass 1.0f for none). */
 int ofri_spline_upsample(ofri_ctx *ctx, const float *src, int rows_in, int cols_in,
                          float *dst, int rows_out, int cols_out, float post_scale);
+/* The two components of a flow in one pair of launches (src/GenericPyramidalOpticalFlow.py:159-162,169-172 upsamples and
+ * scales Uaccum and Vaccum one after the other): the same numbers as two calls of ofri_spline_upsample. */
+int ofri_spline_upsample_pair(ofri_ctx *ctx, const float *src_u, const float *src_v, int rows_in, int cols_in,
+                              float *dst_u, float *dst_v, int rows_out, int cols_out, float scale_u, float scale_v);
 /* doBiLinearWarping (src/GenericPyramidalOpticalFlow.py:70-116): out = img sampled at (cy, cx),
  * clamp-to-edge bilinear, float64 weights. */
 int ofri_warp_coords(ofri_ctx *ctx, const float *img, const float *cy, const float *cx,

@@ -30,6 +30,14 @@ def resize_device(im, size_wh):
     return out
 
 
+def resize_pair_device(im1, im2, size_wh):
+    """Both frames of a level in one launch (reference :336-343)."""
+    w, h = int(size_wh[0]), int(size_wh[1])
+    o1, o2 = im1.ctx.empty((h, w)), im1.ctx.empty((h, w))
+    _ofri.check(_ofri.lib().ofri_resize_bicubic_pair(im1.ctx.handle, im1.ptr, im2.ptr, im1.shape[0], im1.shape[1], o1.ptr, o2.ptr, h, w))
+    return o1, o2
+
+
 def spline_upsample_device(F, shape, post_scale=1.0):
     out = F.ctx.empty(shape)
     _ofri.check(_ofri.lib().ofri_spline_upsample(F.ctx.handle, F.ptr, F.shape[0], F.shape[1], out.ptr,
@@ -65,8 +73,9 @@ def upsample_flow_device(Uacc, Vacc, shape, prev_shape, scale):
     sx = np.float32(np.float32(W) / np.float32(prev_shape[1])) if scale else np.float32(1.0)
     sy = np.float32(np.float32(H) / np.float32(prev_shape[0])) if scale else np.float32(1.0)
     if tuple(prev_shape) != (H, W):
-        us = spline_upsample_device(Uacc, (H, W), sx)
-        vs = spline_upsample_device(Vacc, (H, W), sy)
+        us, vs = ctx.empty((H, W)), ctx.empty((H, W))        # both components in one pair of launches
+        _ofri.check(_ofri.lib().ofri_spline_upsample_pair(ctx.handle, Uacc.ptr, Vacc.ptr, Uacc.shape[0], Uacc.shape[1], us.ptr, vs.ptr,
+                                                          int(H), int(W), float(sx), float(sy)))
     else:
         us, vs = Uacc, Vacc
         if scale:
@@ -148,7 +157,7 @@ def pyramidal_flow_device(im1, im2, FILTER, mainOFlowAlgoAdapter, pyramidalLevel
         prev = work1
         if scale < 1.0 and level != pyramidalLevels:
             wh = (int(np.int32(np.round(cols * scale))), int(np.int32(np.round(rows * scale))))
-            n1, n2 = resize_device(im1, wh), resize_device(im2, wh)
+            n1, n2 = resize_pair_device(im1, im2, wh)
         elif scale > 1.0:
             raise Exception('Invalid scale level: ' + str(scale))
         else:

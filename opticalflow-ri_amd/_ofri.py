@@ -86,8 +86,10 @@ _PROTOS = {
     "ofri_lk_compute": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i], _i),
     "ofri_lk_set_mode": ([_vp, _i], _i),
     "ofri_resize_bicubic": ([_vp, _vp, _i, _i, _vp, _i, _i], _i),
+    "ofri_resize_bicubic_pair": ([_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i], _i),
     "ofri_resize_bilinear": ([_vp, _vp, _i, _i, _vp, _i, _i], _i),
     "ofri_spline_upsample": ([_vp, _vp, _i, _i, _vp, _i, _i, _f], _i),
+    "ofri_spline_upsample_pair": ([_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _f, _f], _i),
     "ofri_warp_coords": ([_vp, _vp, _vp, _vp, _vp, _i, _i], _i),
     "ofri_warp_flow": ([_vp, _vp, _vp, _vp, _f, _vp, _i, _i], _i),
     "ofri_warp_pair": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i], _i),

@@ -130,13 +130,15 @@ __global__ void k_resample_x_rows(const float *__restrict__ in, int H, int W_in,
 // x pass: wavefront w takes the input rows rlo + w, rlo + w + 4, ...; a row segment goes through the
 // wavefront's own LDS line (written and read by that wavefront only, so no workgroup barrier), and the
 // segments of the next two rows are already on their way in registers.
+struct ResizeImages { const float *src[2]; float *dst[2]; };     // the images of one launch (blockIdx.z)
 #define RF_TX 64
 #define RF_TY 16
 #define RF_ROWS 48                       // input rows a tile may need (16 outputs at 2:1 need 38)
 #define RF_SEG 160                       // input columns a tile may need (64 outputs at 2:1 need 137)
 __global__ void __launch_bounds__(256)
-k_resize_fused(const float *__restrict__ in, int H_in, int W_in, float *__restrict__ out, int H_out, int W_out,
-               ResampleTable tx, ResampleTable ty) {
+k_resize_fused(ResizeImages im, int H_in, int W_in, int H_out, int W_out, ResampleTable tx, ResampleTable ty) {
+    const float *__restrict__ in = im.src[blockIdx.z];
+    float *__restrict__ out = im.dst[blockIdx.z];
     __shared__ float hrow[RF_ROWS][RF_TX];
     __shared__ float seg[4][RF_SEG];                                   // one input row segment per wavefront
     const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;           // 64 x 4
@@ -221,58 +223,71 @@ static void resample_launch(ofri_ctx *ctx, dim3 g, dim3 b, const float *in, int 
     else k_resample<AXIS, 0><<<g, b, 0, ctx->stream>>>(in, H_in, W_in, out, H_out, W_out, t);
 }
 
-static int resize_generic(ofri_ctx *ctx, const float *src, int rows_in, int cols_in, float *dst,
+// n images (1 or 2) of the same shapes
+static int resize_generic(ofri_ctx *ctx, int n, const float *const *srcs, int rows_in, int cols_in, float *const *dsts,
                           int rows_out, int cols_out, int filter) {
     OFRI_TRY(ofri_check_ctx(ctx));
-    OFRI_REQUIRE(src && dst, "null pointer");
+    for (int k = 0; k < n; ++k) {
+        OFRI_REQUIRE(srcs[k] && dsts[k], "null pointer");
+        OFRI_REQUIRE(srcs[k] != dsts[k] && srcs[k] != dsts[n - 1 - k], "resize cannot run in place");
+    }
+    OFRI_REQUIRE(n == 1 || dsts[0] != dsts[1], "aliased pointer");
     OFRI_REQUIRE(rows_in > 0 && cols_in > 0 && rows_out > 0 && cols_out > 0, "bad shape");
-    OFRI_REQUIRE(src != dst, "resize cannot run in place");
     const bool need_h = cols_out != cols_in, need_v = rows_out != rows_in;
     if (!need_h && !need_v) {
-        OFRI_TRY(ofri_dev_copy(ctx, dst, src, (size_t)rows_in * cols_in * sizeof(float)));
+        for (int k = 0; k < n; ++k) OFRI_TRY(ofri_dev_copy(ctx, dsts[k], srcs[k], (size_t)rows_in * cols_in * sizeof(float)));
         return OFRI_OK;
     }
-    dim3 b(64, 4);
-    const float *cur = src;
-    PoolBuf tmp(ctx);
     if (need_h && need_v) {
         ResampleTable th, tv;
         OFRI_TRY(get_resample_table(ctx, cols_in, cols_out, filter, &th));
         OFRI_TRY(get_resample_table(ctx, rows_in, rows_out, filter, &tv));
         if (resize_fused_fits(cols_in, cols_out, th, filter, RF_TX, RF_SEG) && resize_fused_fits(rows_in, rows_out, tv, filter, RF_TY, RF_ROWS)) {
-            dim3 g(ceil_div(cols_out, RF_TX), ceil_div(rows_out, RF_TY));
-            k_resize_fused<<<g, 256, 0, ctx->stream>>>(src, rows_in, cols_in, dst, rows_out, cols_out, th, tv);
+            const ResizeImages im = {{srcs[0], srcs[n - 1]}, {dsts[0], dsts[n - 1]}};
+            dim3 g(ceil_div(cols_out, RF_TX), ceil_div(rows_out, RF_TY), n);
+            k_resize_fused<<<g, 256, 0, ctx->stream>>>(im, rows_in, cols_in, rows_out, cols_out, th, tv);
             OFRI_LAUNCH_CHECK();
             return OFRI_OK;
         }
     }
-    if (need_h) {
-        ResampleTable t;
-        OFRI_TRY(get_resample_table(ctx, cols_in, cols_out, filter, &t));
-        float *o = dst;
-        if (need_v) { OFRI_TRY(tmp.get((size_t)rows_in * cols_out * sizeof(float))); o = tmp.as<float>(); }
-        dim3 g(ceil_div(cols_out, 64), ceil_div(rows_in, 4));
-        resample_launch<1>(ctx, g, b, cur, rows_in, cols_in, o, rows_in, cols_out, t);
-        OFRI_LAUNCH_CHECK();
-        cur = o;
-    }
-    if (need_v) {
-        ResampleTable t;
-        OFRI_TRY(get_resample_table(ctx, rows_in, rows_out, filter, &t));
-        dim3 g(ceil_div(cols_out, 64), ceil_div(rows_out, 4));
-        resample_launch<0>(ctx, g, b, cur, rows_in, cols_out, dst, rows_out, cols_out, t);
-        OFRI_LAUNCH_CHECK();
+    dim3 b(64, 4);
+    for (int k = 0; k < n; ++k) {
+        const float *cur = srcs[k];
+        PoolBuf tmp(ctx);
+        if (need_h) {
+            ResampleTable t;
+            OFRI_TRY(get_resample_table(ctx, cols_in, cols_out, filter, &t));
+            float *o = dsts[k];
+            if (need_v) { OFRI_TRY(tmp.get((size_t)rows_in * cols_out * sizeof(float))); o = tmp.as<float>(); }
+            dim3 g(ceil_div(cols_out, 64), ceil_div(rows_in, 4));
+            resample_launch<1>(ctx, g, b, cur, rows_in, cols_in, o, rows_in, cols_out, t);
+            OFRI_LAUNCH_CHECK();
+            cur = o;
+        }
+        if (need_v) {
+            ResampleTable t;
+            OFRI_TRY(get_resample_table(ctx, rows_in, rows_out, filter, &t));
+            dim3 g(ceil_div(cols_out, 64), ceil_div(rows_out, 4));
+            resample_launch<0>(ctx, g, b, cur, rows_in, cols_out, dsts[k], rows_out, cols_out, t);
+            OFRI_LAUNCH_CHECK();
+        }
     }
     return OFRI_OK;
 }
 
 extern "C" int ofri_resize_bicubic(ofri_ctx *ctx, const float *src, int rows_in, int cols_in,
                                    float *dst, int rows_out, int cols_out) {
-    return resize_generic(ctx, src, rows_in, cols_in, dst, rows_out, cols_out, 0);
+    return resize_generic(ctx, 1, &src, rows_in, cols_in, &dst, rows_out, cols_out, 0);
+}
+extern "C" int ofri_resize_bicubic_pair(ofri_ctx *ctx, const float *src1, const float *src2, int rows_in, int cols_in,
+                                        float *dst1, float *dst2, int rows_out, int cols_out) {
+    const float *srcs[2] = {src1, src2};
+    float *dsts[2] = {dst1, dst2};
+    return resize_generic(ctx, 2, srcs, rows_in, cols_in, dsts, rows_out, cols_out, 0);
 }
 extern "C" int ofri_resize_bilinear(ofri_ctx *ctx, const float *src, int rows_in, int cols_in,
                                     float *dst, int rows_out, int cols_out) {
-    return resize_generic(ctx, src, rows_in, cols_in, dst, rows_out, cols_out, 1);
+    return resize_generic(ctx, 1, &src, rows_in, cols_in, &dst, rows_out, cols_out, 1);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -27,6 +27,8 @@
 struct SplineSolveTable { const double *ctab; double lam; int settle; };   // ctab: device, SP_NTAB entries
 // per axis: k[N] knot interval of a fine index, w[4N] = A, B, alpha, beta, first[n] = fine indices below knot interval k
 struct SplineAxisTable { const int *k; const double *w; const int *first; };
+// the fields of one launch (blockIdx.z): the two components of a flow are upsampled together
+struct SplineFields { const float *src[2]; double *mx[2]; float *dst[2]; float scale[2]; };
 
 static int get_spline_solve(ofri_ctx *ctx, SplineSolveTable *t) {
     double c[SP_NTAB];
@@ -158,7 +160,9 @@ __device__ __forceinline__ bool spline_interior(int a, int n, int settle) {
 #define XS_PITCH (XS_SPAN | 1)                        // odd: lanes (rows) fall into different banks
 #define XS_OPITCH (XS_KNOTS + 1)
 __global__ void __launch_bounds__(XS_ROWS *XS_NSUB)
-k_spline_xsolve(const float *__restrict__ Y, double *__restrict__ Mx, int n_r, int n_c, SplineSolveTable t) {
+k_spline_xsolve(SplineFields fl, int n_r, int n_c, SplineSolveTable t) {
+    const float *__restrict__ Y = fl.src[blockIdx.z];
+    double *__restrict__ Mx = fl.mx[blockIdx.z];
     __shared__ double lds[XS_ROWS * XS_OPITCH];       // first the float samples, then the float64 results
     __shared__ double fac[3][XS_KNOTS + 2 * SP_WARM + 4];
     static_assert(sizeof(float) * XS_ROWS * XS_PITCH <= sizeof(double) * XS_ROWS * XS_OPITCH, "staging fits");
@@ -222,8 +226,11 @@ k_spline_xsolve(const float *__restrict__ Y, double *__restrict__ Mx, int n_r, i
 #define YE_PB 12
 template <bool SCALE>
 __global__ void __launch_bounds__(YE_NT, 2)
-k_spline_ysolve_eval(const float *__restrict__ Y, const double *__restrict__ Mx, float *__restrict__ out, int n_r,
-                     int n_c, int N_c, SplineSolveTable ts, SplineAxisTable ay, SplineAxisTable ax, float post_scale) {
+k_spline_ysolve_eval(SplineFields fl, int n_r, int n_c, int N_c, SplineSolveTable ts, SplineAxisTable ay, SplineAxisTable ax) {
+    const float *__restrict__ Y = fl.src[blockIdx.z];
+    const double *__restrict__ Mx = fl.mx[blockIdx.z];
+    float *__restrict__ out = fl.dst[blockIdx.z];
+    const float post_scale = fl.scale[blockIdx.z];
     static_assert(YE_CELLS % YE_Q == 0 && YE_WROWS >= YE_GR && YE_GR % YE_EB == 0, "tile shape");
     __shared__ double G[YE_GR + 1][2][YE_COLS];       // last row: sink for the rows an interval does not have
     __shared__ double WR[YE_WROWS][4];
@@ -339,35 +346,53 @@ k_spline_ysolve_eval(const float *__restrict__ Y, const double *__restrict__ Mx,
     }
 }
 
-extern "C" int ofri_spline_upsample(ofri_ctx *ctx, const float *src, int rows_in, int cols_in,
-                                    float *dst, int rows_out, int cols_out, float post_scale) {
+// nf fields (1 or 2) of the same shapes in one pair of launches
+static int spline_upsample_fields(ofri_ctx *ctx, int nf, const float *const *src, float *const *dst, const float *scale, int rows_in,
+                                  int cols_in, int rows_out, int cols_out) {
     OFRI_TRY(ofri_check_ctx(ctx));
-    OFRI_REQUIRE(src && dst && src != dst, "null or aliased pointer");
+    for (int f = 0; f < nf; ++f) OFRI_REQUIRE(src[f] && dst[f] && src[f] != dst[f], "null or aliased pointer");
+    OFRI_REQUIRE(nf == 1 || (dst[0] != dst[1] && dst[0] != src[1] && dst[1] != src[0]), "aliased pointer");
     OFRI_REQUIRE(rows_in >= 4 && cols_in >= 4, "cubic spline needs at least 4 samples per axis (got %d x %d)", rows_in, cols_in);
     OFRI_REQUIRE(rows_out > 0 && cols_out > 0, "bad output shape");
     OFRI_REQUIRE((long long)rows_in * cols_in < (1LL << 31) && (long long)rows_out * cols_out < (1LL << 33), "field too large");
-    SplineSolveTable s0, s1;
+    SplineSolveTable s0;
     SplineAxisTable a0, a1;
     OFRI_TRY(get_spline_solve(ctx, &s0));
-    s1 = s0;
     OFRI_TRY(get_spline_axis(ctx, rows_in, rows_out, &a0));
     OFRI_TRY(get_spline_axis(ctx, cols_in, cols_out, &a1));
+    const size_t plane = (size_t)rows_in * cols_in;
     PoolBuf Mx(ctx);
-    OFRI_TRY(Mx.get((size_t)rows_in * cols_in * sizeof(double)));
+    OFRI_TRY(Mx.get(nf * plane * sizeof(double)));
+    SplineFields fl;
+    bool scaled = false;
+    for (int f = 0; f < 2; ++f) {
+        const int g = f < nf ? f : 0;
+        fl.src[f] = src[g]; fl.dst[f] = dst[g]; fl.mx[f] = Mx.as<double>() + g * plane; fl.scale[f] = scale[g];
+        scaled = scaled || scale[g] != 1.0f;
+    }
     {
-        dim3 g(ceil_div(cols_in, XS_KNOTS), ceil_div(rows_in, XS_ROWS));
-        k_spline_xsolve<<<g, XS_ROWS * XS_NSUB, 0, ctx->stream>>>(src, Mx.as<double>(), rows_in, cols_in, s1);
+        dim3 g(ceil_div(cols_in, XS_KNOTS), ceil_div(rows_in, XS_ROWS), nf);
+        k_spline_xsolve<<<g, XS_ROWS * XS_NSUB, 0, ctx->stream>>>(fl, rows_in, cols_in, s0);
         OFRI_LAUNCH_CHECK();
     }
     {
-        dim3 g(ceil_div(cols_in - 1, YE_COLS - 1), ceil_div(rows_in - 1, YE_CELLS));
-        if (post_scale != 1.0f)
-            k_spline_ysolve_eval<true><<<g, YE_NT, 0, ctx->stream>>>(src, Mx.as<double>(), dst, rows_in, cols_in, cols_out,
-                                                                            s0, a0, a1, post_scale);
-        else
-            k_spline_ysolve_eval<false><<<g, YE_NT, 0, ctx->stream>>>(src, Mx.as<double>(), dst, rows_in, cols_in, cols_out,
-                                                                             s0, a0, a1, post_scale);
+        dim3 g(ceil_div(cols_in - 1, YE_COLS - 1), ceil_div(rows_in - 1, YE_CELLS), nf);
+        // (a product with 1.0f is the number itself: one scaled field makes both take the multiplication)
+        if (scaled) k_spline_ysolve_eval<true><<<g, YE_NT, 0, ctx->stream>>>(fl, rows_in, cols_in, cols_out, s0, a0, a1);
+        else k_spline_ysolve_eval<false><<<g, YE_NT, 0, ctx->stream>>>(fl, rows_in, cols_in, cols_out, s0, a0, a1);
         OFRI_LAUNCH_CHECK();
     }
     return OFRI_OK;
+}
+
+extern "C" int ofri_spline_upsample(ofri_ctx *ctx, const float *src, int rows_in, int cols_in,
+                                    float *dst, int rows_out, int cols_out, float post_scale) {
+    return spline_upsample_fields(ctx, 1, &src, &dst, &post_scale, rows_in, cols_in, rows_out, cols_out);
+}
+extern "C" int ofri_spline_upsample_pair(ofri_ctx *ctx, const float *src_u, const float *src_v, int rows_in, int cols_in,
+                                         float *dst_u, float *dst_v, int rows_out, int cols_out, float scale_u, float scale_v) {
+    const float *src[2] = {src_u, src_v};
+    float *dst[2] = {dst_u, dst_v};
+    const float scale[2] = {scale_u, scale_v};
+    return spline_upsample_fields(ctx, 2, src, dst, scale, rows_in, cols_in, rows_out, cols_out);
 }
