@@ -22,7 +22,7 @@ static double linear_w(double x) {
     return x < 1.0 ? 1.0 - x : 0.0;
 }
 
-struct ResampleTable { int ksize, n_out; const int *bounds; const double *w; };   // device pointers; w is tap-major: w[tap*n_out + out]
+struct ResampleTable { int ksize, n_out, maxcnt; const int *bounds; const double *w; };   // maxcnt: longest window   // device pointers; w is tap-major: w[tap*n_out + out]
 
 static int get_resample_table(ofri_ctx *ctx, int n_in, int n_out, int filter, ResampleTable *t) {
     const double support0 = filter == 0 ? 2.0 : 1.0;
@@ -51,7 +51,14 @@ static int get_resample_table(ofri_ctx *ctx, int n_in, int n_out, int filter, Re
         OFRI_TRY(ofri_cached_table(ctx, key + "b", bounds.data(), bounds.size() * sizeof(int), &pb));
         OFRI_TRY(ofri_cached_table(ctx, key + "w", w.data(), w.size() * sizeof(double), &pw));
     }
-    t->ksize = ksize; t->n_out = n_out; t->bounds = (const int *)pb; t->w = (const double *)pw;
+    int maxcnt = 0;                                   // (integer work on n_out entries: cheaper to redo than to cache)
+    for (int o = 0; o < n_out; ++o) {
+        const double c = (o + 0.5) * scale;
+        int lo = (int)(c - sup + 0.5); if (lo < 0) lo = 0;
+        int hi = (int)(c + sup + 0.5); if (hi > n_in) hi = n_in;
+        if (hi - lo > maxcnt) maxcnt = hi - lo;
+    }
+    t->ksize = ksize; t->n_out = n_out; t->maxcnt = maxcnt; t->bounds = (const int *)pb; t->w = (const double *)pw;
     return OFRI_OK;
 }
 
@@ -132,29 +139,31 @@ __global__ void k_resample_x_rows(const float *__restrict__ in, int H, int W_in,
 // segments of the next two rows are already on their way in registers.
 struct ResizeImages { const float *src[2]; float *dst[2]; };     // the images of one launch (blockIdx.z)
 #define RF_TX 64
-#define RF_TY 16
+#define RF_TY 16                         // (32 and 64 rows measured: 7 and 15 % slower at 4096 -> 2048)
 #define RF_ROWS 48                       // input rows a tile may need (16 outputs at 2:1 need 38)
 #define RF_SEG 160                       // input columns a tile may need (64 outputs at 2:1 need 137)
+// KT: no window is longer than KT taps (9 by construction; 8 for the 2:1 reduction of a pyramid level)
+template <int KT>
 __global__ void __launch_bounds__(256)
 k_resize_fused(ResizeImages im, int H_in, int W_in, int H_out, int W_out, ResampleTable tx, ResampleTable ty) {
     const float *__restrict__ in = im.src[blockIdx.z];
     float *__restrict__ out = im.dst[blockIdx.z];
     __shared__ float hrow[RF_ROWS][RF_TX];
     __shared__ float seg[4][RF_SEG];                                   // one input row segment per wavefront
-    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;           // 64 x 4
+    const int lx = threadIdx.x & 63, ly = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);           // 64 x 4
     const int xb = blockIdx.x * RF_TX, x = xb + lx, y0 = blockIdx.y * RF_TY;
     const int ylast = min(y0 + RF_TY, H_out) - 1, xlast = min(xb + RF_TX, W_out) - 1;
     const int rlo = ty.bounds[2 * y0], rhi = min(ty.bounds[2 * ylast] + ty.bounds[2 * ylast + 1], rlo + RF_ROWS);   // uniform
     const int xlo = tx.bounds[2 * xb], span = min(tx.bounds[2 * xlast] + tx.bounds[2 * xlast + 1] - xlo, RF_SEG);
-    double w[9];
-    int off[9];
+    double w[KT];
+    int off[KT];
     {
         const int xc = min(x, W_out - 1);
         const int lo = tx.bounds[2 * xc], cnt = tx.bounds[2 * xc + 1];
         const double *k = tx.w + xc;
         const size_t ks = (size_t)tx.n_out;
 #pragma unroll
-        for (int i = 0; i < 9; ++i) {
+        for (int i = 0; i < KT; ++i) {
             off[i] = min(lo + (i < cnt ? i : (cnt > 0 ? cnt - 1 : 0)) - xlo, RF_SEG - 1);
             w[i] = i < cnt ? k[i * ks] : 0.0;
         }
@@ -178,7 +187,7 @@ k_resize_fused(ResizeImages im, int H_in, int W_in, int H_out, int W_out, Resamp
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         double ss = 0.0;
 #pragma unroll
-        for (int i = 0; i < 9; ++i) ss = __dadd_rn(ss, __dmul_rn((double)line[off[i]], w[i]));
+        for (int i = 0; i < KT; ++i) ss = __dadd_rn(ss, __dmul_rn((double)line[off[i]], w[i]));
         hrow[r - rlo][lx] = (float)ss;
         __builtin_amdgcn_wave_barrier();                                // the line is rewritten after these reads
         a0 = b0; a1 = b1; a2 = b2;
@@ -188,14 +197,14 @@ k_resize_fused(ResizeImages im, int H_in, int W_in, int H_out, int W_out, Resamp
     if (x >= W_out) return;
 #pragma unroll
     for (int j = 0; j < RF_TY / 4; ++j) {
-        const int y = y0 + ly + 4 * j;
+        const int y = y0 + ly + 4 * j;                                  // the same for the whole wavefront: window and weights are scalar loads
         if (y >= H_out) break;
         const int lo = ty.bounds[2 * y], cnt = ty.bounds[2 * y + 1];
         const double *k = ty.w + y;
         const size_t ks = (size_t)ty.n_out;
         double ss = 0.0;
 #pragma unroll
-        for (int i = 0; i < 9; ++i) {
+        for (int i = 0; i < KT; ++i) {
             const int ii = i < cnt ? i : (cnt > 0 ? cnt - 1 : 0);
             const double wi = i < cnt ? k[i * ks] : 0.0;
             ss = __dadd_rn(ss, __dmul_rn((double)hrow[lo + ii - rlo][lx], wi));
@@ -245,7 +254,10 @@ static int resize_generic(ofri_ctx *ctx, int n, const float *const *srcs, int ro
         if (resize_fused_fits(cols_in, cols_out, th, filter, RF_TX, RF_SEG) && resize_fused_fits(rows_in, rows_out, tv, filter, RF_TY, RF_ROWS)) {
             const ResizeImages im = {{srcs[0], srcs[n - 1]}, {dsts[0], dsts[n - 1]}};
             dim3 g(ceil_div(cols_out, RF_TX), ceil_div(rows_out, RF_TY), n);
-            k_resize_fused<<<g, 256, 0, ctx->stream>>>(im, rows_in, cols_in, rows_out, cols_out, th, tv);
+            const int mc = th.maxcnt > tv.maxcnt ? th.maxcnt : tv.maxcnt;
+            if (mc <= 5) k_resize_fused<5><<<g, 256, 0, ctx->stream>>>(im, rows_in, cols_in, rows_out, cols_out, th, tv);
+            else if (mc <= 8) k_resize_fused<8><<<g, 256, 0, ctx->stream>>>(im, rows_in, cols_in, rows_out, cols_out, th, tv);
+            else k_resize_fused<9><<<g, 256, 0, ctx->stream>>>(im, rows_in, cols_in, rows_out, cols_out, th, tv);
             OFRI_LAUNCH_CHECK();
             return OFRI_OK;
         }
