@@ -1,5 +1,5 @@
 #!/bin/bash
-# one SQ counter pass over the headline pair's kernels (measurement helper): bash tools/_pmc_probe.sh <lib> <counters...>
+# one SQ counter pass over the headline pair's kernels (measurement helper): bash tools/pmc_probe.sh <lib> <counters...>
 cd /tmp && export TMPDIR=/tmp
 lib=$1; shift
 rm -rf /tmp/pmc_$lib

@@ -1,5 +1,5 @@
 #!/bin/bash
-# per-kernel average durations of the headline pair for several builds (measurement helper)
+# per-kernel average durations of the headline pair for several builds, from rocprofv3 kernel traces: bash tools/prof_variants.sh <lib>...
 cd /tmp && export TMPDIR=/tmp
 for lib in "$@"; do
   rm -rf /tmp/pv_$lib
