@@ -15,6 +15,7 @@
 #include "ofri_internal.h"
 
 #include <string>
+#include <type_traits>
 #include <vector>
 
 // device: cp[m], 1/den[m], m = n-2.  Away from the ends both are one constant: lam = 2 - sqrt(3), the fixed
@@ -220,8 +221,12 @@ k_spline_xsolve(SplineFields fl, int n_r, int n_c, SplineSolveTable t) {
 #define YE_COLS 64
 #define YE_NT (2 * YE_COLS)
 #define YE_Q 9                      // knot intervals per quarter
+#ifndef YE_GR
 #define YE_GR 24                    // fine rows per pass over a quarter (one pass up to a factor of 3)
-#define YE_EB 8                     // fine rows a thread turns into pixels at a time
+#endif
+#ifndef YE_EB
+#define YE_EB 6                     // fine rows a thread turns into pixels at a time (a factor of 2 makes 18 rows per quarter: three full turns)
+#endif
 #define YE_WROWS 96                 // fine rows whose weights are staged at a time
 #define YE_PB 12
 template <bool SCALE>
@@ -270,18 +275,21 @@ k_spline_ysolve_eval(SplineFields fl, int n_r, int n_c, int N_c, SplineSolveTabl
     const double xa = ax.w[4 * (size_t)jmine], xb = ax.w[4 * (size_t)jmine + 1], xal = ax.w[4 * (size_t)jmine + 2],
                  xbe = ax.w[4 * (size_t)jmine + 3];
     // rows i0 .. i0+nr-1 (nr <= YE_EB) from G[g0 ...] to fine column j
-    auto emit = [&](int j, int cc, double wa, double wb, double wal, double wbe, int g0, int i0, int nr) {
+    // full: all YE_EB rows exist (no test per row: the rows' reads and arithmetic interleave)
+    auto emit = [&](auto full, int j, int cc, double wa, double wb, double wal, double wbe, int g0, int i0, int nr) {
         double v[YE_EB];
 #pragma unroll
         for (int r = 0; r < YE_EB; ++r) {
             const double *g = &G[g0 + r][0][cc], *h = &G[g0 + r][1][cc];
             v[r] = wa * g[0] + wb * g[1] + wal * h[0] + wbe * h[1];
         }
+        float *o = out + (size_t)i0 * N_c + j;
 #pragma unroll
         for (int r = 0; r < YE_EB; ++r) {
             float f = (float)v[r];
             if (SCALE) f = __fmul_rn(f, post_scale);
-            if (r < nr) out[(size_t)(i0 + r) * N_c + j] = f;
+            if (decltype(full)::value || r < nr) *o = f;
+            o += N_c;
         }
     };
     auto row_value = [&](int li, double ya, double yb, double Ma, double Mb) {
@@ -335,10 +343,14 @@ k_spline_ysolve_eval(SplineFields fl, int n_r, int n_c, int N_c, SplineSolveTabl
             __syncthreads();
             for (int rb = 0; rb < pe - pb; rb += YE_EB) {
                 const int nr = min(YE_EB, pe - pb - rb);
-                if (jf0 + tid < jf1) emit(jf0 + tid, cmine, xa, xb, xal, xbe, rb, pb + rb, nr);
+                if (nr == YE_EB) {
+                    if (jf0 + tid < jf1) emit(std::true_type(), jf0 + tid, cmine, xa, xb, xal, xbe, rb, pb + rb, nr);
+                } else {
+                    if (jf0 + tid < jf1) emit(std::false_type(), jf0 + tid, cmine, xa, xb, xal, xbe, rb, pb + rb, nr);
+                }
                 for (int j = jf0 + tid + YE_NT; j < jf1; j += YE_NT) {     // more than two fine columns per knot interval
                     const double *w = ax.w + 4 * (size_t)j;
-                    emit(j, ax.k[j] - tx0, w[0], w[1], w[2], w[3], rb, pb + rb, nr);
+                    emit(std::false_type(), j, ax.k[j] - tx0, w[0], w[1], w[2], w[3], rb, pb + rb, nr);
                 }
             }
             __syncthreads();                          // G is rewritten by the next pass
