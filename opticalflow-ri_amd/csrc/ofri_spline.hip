@@ -169,7 +169,11 @@ k_spline_xsolve(SplineFields fl, int n_r, int n_c, SplineSolveTable t) {
     static_assert(sizeof(float) * XS_ROWS * XS_PITCH <= sizeof(double) * XS_ROWS * XS_OPITCH, "staging fits");
     float *in = reinterpret_cast<float *>(lds);
     const int tid = threadIdx.x, l = tid & (XS_ROWS - 1), q = tid / XS_ROWS;
-    const int cx0 = blockIdx.x * XS_KNOTS, r0 = blockIdx.y * XS_ROWS;
+    // an XCD (workgroups go to the 8 XCDs round-robin by index) walks along rows of tiles: the margins that neighbours share
+    // come from its L2
+    const int nbx = gridDim.x, lin = blockIdx.y * nbx + blockIdx.x, per = (nbx * (int)gridDim.y) / 8;
+    const int til = lin < per * 8 ? (lin % 8) * per + lin / 8 : lin;
+    const int cx0 = (til % nbx) * XS_KNOTS, r0 = (til / nbx) * XS_ROWS;
     const int base = cx0 - XS_LEAD;
     const bool inner = spline_interior<XS_KNOTS>(cx0, n_c, t.settle);    // one decision per workgroup
     const SplineFactors fa = {fac[0], fac[1], fac[2], cx0 - 3 - SP_WARM};
@@ -220,7 +224,12 @@ k_spline_xsolve(SplineFields fl, int n_r, int n_c, SplineSolveTable t) {
 #define YE_NK (YE_CELLS + 1)
 #define YE_COLS 64
 #define YE_NT (2 * YE_COLS)
+#ifndef YE_ABL
+#define YE_ABL 0
+#endif
+#ifndef YE_Q
 #define YE_Q 9                      // knot intervals per quarter
+#endif
 #ifndef YE_GR
 #define YE_GR 24                    // fine rows per pass over a quarter (one pass up to a factor of 3)
 #endif
@@ -241,7 +250,12 @@ k_spline_ysolve_eval(SplineFields fl, int n_r, int n_c, int N_c, SplineSolveTabl
     __shared__ double WR[YE_WROWS][4];
     __shared__ double fac[3][YE_NK + 2 + 2 * SP_WARM];
     const int tid = threadIdx.x, arr = __builtin_amdgcn_readfirstlane(tid / YE_COLS), cl = tid % YE_COLS;
-    const int tx0 = blockIdx.x * (YE_COLS - 1), a = blockIdx.y * YE_CELLS;
+    // Workgroups go to the 8 XCDs round-robin by index, and each XCD has its own L2.  Renumber them so that an XCD walks down
+    // columns of tiles: the 48 warm-up rows that vertically adjacent tiles share then come from that L2 instead of memory.
+    const int nbx = gridDim.x, nby = gridDim.y, lin = blockIdx.y * nbx + blockIdx.x, per = (nbx * nby) / 8;
+    const int til = lin < per * 8 ? (lin % 8) * per + lin / 8 : lin;
+    const int bx = til / nby, by = til - bx * nby;
+    const int tx0 = bx * (YE_COLS - 1), a = by * YE_CELLS;
     const int c = min(tx0 + cl, n_c - 1);
     const int N_r = ay.first[n_r - 1];
     const bool inner = spline_interior<YE_NK>(a, n_r, ts.settle);
@@ -288,7 +302,11 @@ k_spline_ysolve_eval(SplineFields fl, int n_r, int n_c, int N_c, SplineSolveTabl
         for (int r = 0; r < YE_EB; ++r) {
             float f = (float)v[r];
             if (SCALE) f = __fmul_rn(f, post_scale);
+#if YE_ABL == 3
+            if (f == 1.2345f) *o = f;
+#else
             if (decltype(full)::value || r < nr) *o = f;
+#endif
             o += N_c;
         }
     };
@@ -312,6 +330,10 @@ k_spline_ysolve_eval(SplineFields fl, int n_r, int n_c, int N_c, SplineSolveTabl
                 __syncthreads();
             }
             bool more = false;
+#if YE_ABL == 5
+            if (pb < 0)
+#endif
+            {
             // weights of the first two fine rows of an interval, fetched one interval ahead of their use
             double wa[4], wb[4];
             auto fetch = [&](int p) {
@@ -332,6 +354,7 @@ k_spline_ysolve_eval(SplineFields fl, int n_r, int n_c, int N_c, SplineSolveTabl
                 G[n >= 2 ? lo + 1 - pb : YE_GR][arr][cl] = gb;
                 more |= n > 2;
             }
+            }
             if (more) {
 #pragma unroll
                 for (int p = 0; p < YE_Q; ++p) {
@@ -341,7 +364,7 @@ k_spline_ysolve_eval(SplineFields fl, int n_r, int n_c, int N_c, SplineSolveTabl
                 }
             }
             __syncthreads();
-            for (int rb = 0; rb < pe - pb; rb += YE_EB) {
+            for (int rb = 0; rb < (YE_ABL == 4 ? 0 : pe - pb); rb += YE_EB) {
                 const int nr = min(YE_EB, pe - pb - rb);
                 if (nr == YE_EB) {
                     if (jf0 + tid < jf1) emit(std::true_type(), jf0 + tid, cmine, xa, xb, xal, xbe, rb, pb + rb, nr);
