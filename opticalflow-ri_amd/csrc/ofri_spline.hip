@@ -224,9 +224,6 @@ k_spline_xsolve(SplineFields fl, int n_r, int n_c, SplineSolveTable t) {
 #define YE_NK (YE_CELLS + 1)
 #define YE_COLS 64
 #define YE_NT (2 * YE_COLS)
-#ifndef YE_ABL
-#define YE_ABL 0
-#endif
 #ifndef YE_Q
 #define YE_Q 9                      // knot intervals per quarter
 #endif
@@ -302,11 +299,7 @@ k_spline_ysolve_eval(SplineFields fl, int n_r, int n_c, int N_c, SplineSolveTabl
         for (int r = 0; r < YE_EB; ++r) {
             float f = (float)v[r];
             if (SCALE) f = __fmul_rn(f, post_scale);
-#if YE_ABL == 3
-            if (f == 1.2345f) *o = f;
-#else
             if (decltype(full)::value || r < nr) *o = f;
-#endif
             o += N_c;
         }
     };
@@ -330,9 +323,6 @@ k_spline_ysolve_eval(SplineFields fl, int n_r, int n_c, int N_c, SplineSolveTabl
                 __syncthreads();
             }
             bool more = false;
-#if YE_ABL == 5
-            if (pb < 0)
-#endif
             {
             // weights of the first two fine rows of an interval, fetched one interval ahead of their use
             double wa[4], wb[4];
@@ -364,7 +354,7 @@ k_spline_ysolve_eval(SplineFields fl, int n_r, int n_c, int N_c, SplineSolveTabl
                 }
             }
             __syncthreads();
-            for (int rb = 0; rb < (YE_ABL == 4 ? 0 : pe - pb); rb += YE_EB) {
+            for (int rb = 0; rb < pe - pb; rb += YE_EB) {
                 const int nr = min(YE_EB, pe - pb - rb);
                 if (nr == YE_EB) {
                     if (jf0 + tid < jf1) emit(std::true_type(), jf0 + tid, cmine, xa, xb, xal, xbe, rb, pb + rb, nr);
