@@ -419,6 +419,31 @@ def test_spline_upsample_small_and_ragged(ctx, shape_in, shape_out):
     assert np.abs(got - want).max() <= 2e-6 * max(1.0, np.abs(want).max())
 
 
+@pytest.mark.parametrize("shape_in,shape_out", [((4, 4), (8, 8)), ((38, 65), (76, 130)), ((45, 70), (225, 77)), ((150, 200), (60, 500)),
+                                                ((600, 700), (1200, 1400))])
+def test_pair_entry_points_equal_two_single_calls(ctx, shape_in, shape_out):
+    """ofri_spline_upsample_pair and ofri_resize_bicubic_pair (both components / both frames in one launch) give the bits of
+    two calls of the single-field entry points, on ragged shapes, other factors and sizes past one tile."""
+    import _ofri
+    import GenericPyramidalOpticalFlow as G
+    lib = _ofri.lib()
+    rng = np.random.default_rng(shape_in[0] + 7 * shape_in[1])
+    a = rng.standard_normal(shape_in).astype(np.float32).cumsum(1).astype(np.float32)
+    b = rng.standard_normal(shape_in).astype(np.float32).cumsum(0).astype(np.float32)
+    da, db = ctx.upload(a), ctx.upload(b)
+    ua, ub = ctx.empty(shape_out), ctx.empty(shape_out)
+    _ofri.check(lib.ofri_spline_upsample_pair(ctx.handle, da.ptr, db.ptr, shape_in[0], shape_in[1], ua.ptr, ub.ptr, shape_out[0], shape_out[1], 2.0, 1.0))
+    np.testing.assert_array_equal(ua.numpy(), G.spline_upsample_device(da, shape_out, 2.0).numpy())
+    np.testing.assert_array_equal(ub.numpy(), G.spline_upsample_device(db, shape_out, 1.0).numpy())
+    for shp in (shape_out, (max(1, shape_in[0] // 2), max(1, shape_in[1] // 2)), (max(1, shape_in[0] // 3), shape_in[1])):
+        ra, rb = G.resize_pair_device(da, db, (shp[1], shp[0]))
+        np.testing.assert_array_equal(ra.numpy(), G.resize_device(da, (shp[1], shp[0])).numpy())
+        np.testing.assert_array_equal(rb.numpy(), G.resize_device(db, (shp[1], shp[0])).numpy())
+    # aliased destinations are refused
+    assert lib.ofri_spline_upsample_pair(ctx.handle, da.ptr, db.ptr, shape_in[0], shape_in[1], ua.ptr, ua.ptr, shape_out[0], shape_out[1], 1.0, 1.0) != 0
+    assert lib.ofri_resize_bicubic_pair(ctx.handle, da.ptr, db.ptr, shape_in[0], shape_in[1], ua.ptr, ua.ptr, shape_out[0], shape_out[1]) != 0
+
+
 # ------------------------------------------------------------------------------ whole driver
 def _driver_case(name, U, V):
     d = load_gold("driver")
