@@ -12,9 +12,7 @@
 #include <cstring>
 
 #define LV_TX 64
-#ifndef LV_TY
-#define LV_TY 32
-#endif
+#define LV_TY 32                         // (16 rows, more workgroups per CU: the same time; 8 rows: 12 % slower)
 #define LV_MAXK 7
 struct LevelTaps { float k[LV_MAXK]; };
 
