@@ -17,7 +17,7 @@ def one(libname):
     ctx = _ofri.Context(0)
     lib = _ofri.lib()
     out = []
-    for n, sweeps in ((4096, 96), (4096, 16), (4096, 100), (2048, 100)):
+    for n, sweeps in [tuple(map(int, x.split(':'))) for x in os.environ.get('HS_TIME_CASES', '4096:96,4096:16,4096:100,2048:100').split(',')]:
         rng = np.random.default_rng(0)
         pl = [ctx.upload(rng.standard_normal((n, n)).astype(np.float32)) for _ in range(5)]
 
