@@ -11,7 +11,9 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 for r in rows:
     n = r["Name"]
-    if "level_coefs" in n or "resize" in n or "spline" in n:
+    import os
+    pat = os.environ.get("PROF_KERNELS", "level_coefs,resize,spline").split(",")
+    if any(q in n for q in pat):
         print("   %-50s calls %5s avg %9.1f us" % (n[:50], r["Calls"], float(r["AverageNs"]) / 1e3))
 PY
 done
