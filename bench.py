@@ -215,7 +215,7 @@ def roofline_block(recs, H, W, steps, ms_per_step, streaming=None):
     block = {
         "bound": ("hbm" if mem_bound else "issue") if blocked else "hbm",
         "bound_basis": None if not blocked else
-        "counted traffic moves at %s GB/s against %s GB/s of the one-sweep kernel in the same run; SIMD issue slots taken: %s (vector: %s)" % (
+        "counted traffic moves at %s GB/s against %s GB/s of the one-sweep kernel in the same run; instructions issued per SIMD and quad-cycle at 2.4 GHz, all kinds: %s (scalar, LDS and memory instructions can issue beside a vector one, so this can pass 1), vector: %s" % (
             ("%.0f" % (hbm_meas * HBM_PEAK_GBS)) if hbm_meas is not None else "?", ("%.0f" % stream_gbs) if stream_gbs else "?",
             (sq or {}).get("simd_any_issue", "?"), (sq or {}).get("simd_valu_issue", "?")),
         "kernel": key, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
