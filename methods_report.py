@@ -53,8 +53,8 @@ def make_adapter(family, levels, liu_shen):
 
 def load_pair(args):
     if args.pair:
-        from PIL import Image
-        a, b = (np.array(Image.open(p)).astype(np.float32) for p in args.pair)
+        from piv_io import imread                            # tifffile, Pillow or the built-in TIFF reader, whichever is there
+        a, b = (imread(p).astype(np.float32) for p in args.pair)
     elif args.synth:
         from piv_synth import synth_piv
         a, b = synth_piv(args.synth, args.synth, seed=0)
